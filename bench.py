@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- acoustic frames/s of the quantized scorer on 1..N MI355X.
+
+A "step" is one pass of the whole hot path (QuantizedDnn.calculate: shift/scale,
+fp32 layer 0, six int8 2048x2048 layers, int8 8000x2048 output layer, soft-max)
+over one 10 000-frame batch per GPU of the synthetic 7x2048 -> 8000 net
+(BASELINE.json configs[2]; configs[1]'s "model" file is a feature batch, see
+SURVEY.md section 0).  Inputs and outputs are device resident; the weights are
+quantized once on rank 0 and broadcast over RCCL at load time only; there is no
+collective in the timed region (frames are independent: weak scaling).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) including
+`roofline` for the dominant kernel (the int8 hidden-layer GEMM, measured with
+HIP events on its launch stream in a second pass over the same K steps) and
+`cpu_baseline` (the SSE4.1 oracle port timed on this host, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FRAMES_PER_GPU = 10000
+INT8_PEAK_TOPS = 5000.0  # dense int8 MFMA, 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
+HIDDEN_OPS_PER_FRAME = 2 * 2048 * 2048  # one hidden layer, int8 ops
+INT8_OPS_PER_FRAME = 83_099_648  # 6*2048^2 + 8000*2048 MAC, x2
+
+
+def cpu_baseline(model_path: str, sample_utts: int = 4, frames: int = 100):
+    """The reference algorithm (oracle SSE4.1 port, frame-block 8) on this host:
+    one thread, then one context per thread on independent 100-frame utterances
+    (the reference's own concurrency model, MultiThreadedStressTest.java:48-61)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from fast_dnn_amd import formats as F
+    from oracle.oracle import Oracle
+
+    orc = Oracle(model_path)
+    utts = [F.synth_features(frames, seed=900 + i) for i in range(8)]
+    orc.calculate(utts[0], batch=8, sse=True)  # warm-up
+    t = []
+    for i in range(sample_utts):
+        t0 = time.perf_counter()
+        orc.calculate(utts[i % len(utts)], batch=8, sse=True)
+        t.append(time.perf_counter() - t0)
+    one = frames / float(np.median(t))
+    cores = len(os.sched_getaffinity(0))
+    threads = max(1, cores)
+    per_thread = 2
+    with ThreadPoolExecutor(threads) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(lambda i: orc.calculate(utts[i % len(utts)], batch=8, sse=True), range(threads * per_thread)))
+        dt = time.perf_counter() - t0
+    many = threads * per_thread * frames / dt
+    return {
+        "value": round(many, 1), "unit": "frames/s", "cores": threads, "kind": "port",
+        "value_1thread": round(one, 1),
+        "sample": f"oracle SSE4.1 port (pmaddubsw, frame-block 8) of the same net: {sample_utts} x {frames}-frame utterances "
+                  f"on 1 thread (median), then {threads * per_thread} utterances on {threads} threads, one context each",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--mode", default="gauss", choices=["gauss", "nosat"], help="synthetic weight distribution")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from fast_dnn_amd import api, formats as F
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available() or api.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: the scorer has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from fast_dnn_amd.dist import load_replicated
+
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    model_path = os.path.join(tmp, f"fdnn_net_seed1_{args.mode}.bin")
+    if rank == 0:
+        F.ensure_model_file(model_path, F.NET_TOPOLOGY, seed=1, mode=args.mode)
+    dnn = load_replicated(model_path, local, rank, world)
+    O = dnn.outputDimension()
+    n = args.frames
+
+    x = torch.from_numpy(F.synth_features(n, 432, seed=1000 + rank)).to(dev)
+    out = torch.empty((n, O), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        dnn.calculate_device(x.data_ptr(), n, out.data_ptr(), stream.cuda_stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity on the last output: soft-max rows sum to one
+    row_sum = float(out[:64].sum(1).mean().item())
+    assert abs(row_sum - 1.0) < 1e-3, row_sum
+
+    # second pass over the same K steps with per-kernel HIP events (rank 0 reports)
+    dnn.profileBegin()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    prof = dnn.profileEnd()
+
+    if rank == 0:
+        hid = prof["hidden_gemm"]
+        hid_ms = hid["ms"] / max(hid["launches"], 1)
+        achieved = HIDDEN_OPS_PER_FRAME * n / (hid_ms * 1e-3) / 1e12
+        kernels_ms = {k: round(v["ms"] / args.steps, 4) for k, v in prof.items()}
+        res = {
+            "metric": "acoustic frames/sec (whole node), 7x2048->8000 nnet",
+            "value": round(world * n * args.steps / elapsed, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int8 (u8 activations x s8 weights -> int32; fp32 layer 0 and soft-max)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[2]: synthetic Kaldi nnet 432 -> 7x2048 -> 8000 ({args.mode} weights, seed 1), "
+                            f"{n}-frame batch per GPU, full soft-max, device-resident in/out",
+                "frames_per_gpu": n, "global_frames": world * n, "parallelism": f"frame-sharded x{world}, replicated weights",
+            },
+            "x_realtime_per_gpu": round(n * args.steps / elapsed / 100.0, 1),
+            "int8_tops_end_to_end": round(INT8_OPS_PER_FRAME * n * args.steps / elapsed / 1e12, 1),
+            "roofline": {
+                "kernel": "qgemm_kernel<hidden> (int8 MFMA 2048x2048 layer + dequant/bias/sigmoid-LUT epilogue)",
+                "bound": "mfma", "achieved": round(achieved, 1), "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
+                "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": None,
+                "avg_launch_ms": round(hid_ms, 4), "launches": hid["launches"],
+            },
+            "kernel_ms_per_step": kernels_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(model_path)
+        print(json.dumps(res), flush=True)
+    dnn.delete()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,375 @@
+"""Python mirror of ``suskun.nn.QuantizedDnn`` over the C-ABI of libfast-dnn.so.
+
+Same names, argument meaning and error behaviour as the Java facade
+(src/java/suskun/nn/QuantizedDnn.java), so tests read like the reference's own
+FuncTest / MultiThreadedStressTest.  This module is a binding only: every
+computation happens in the HIP library; there is no fallback, and importing
+works without a GPU only so that host-side helpers and symbol checks can run.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfast-dnn.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+FDNN_OK, FDNN_E_ARG, FDNN_E_IO, FDNN_E_FORMAT, FDNN_E_DEVICE, FDNN_E_NOMEM, FDNN_E_STATE = 0, -1, -2, -3, -4, -5, -6
+
+
+class FdnnError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"fdnn error {code}: {msg}")
+        self.code = code
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libfast-dnn.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-C", CSRC, "all"] + ([] if verbose else ["-s"]))
+    return LIB_PATH
+
+
+_lib = None
+
+_c_f32p = C.POINTER(C.c_float)
+_c_i8p = C.POINTER(C.c_int8)
+_c_u8p = C.POINTER(C.c_uint8)
+_c_i32p = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); also the list of exported C-ABI symbols that
+# include/fdnn.h declares (tests check both directions)
+SIGNATURES = {
+    "fdnn_last_error": (C.c_char_p, []),
+    "fdnn_version": (C.c_char_p, []),
+    "fdnn_device_count": (C.c_int, []),
+    "fdnn_model_load": (C.c_int, [C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),
+    "fdnn_model_load_on": (C.c_int, [C.c_char_p, C.c_float, C.c_int, C.POINTER(C.c_void_p)]),
+    "fdnn_model_free": (None, [C.c_void_p]),
+    "fdnn_model_input_dim": (C.c_int, [C.c_void_p]),
+    "fdnn_model_output_dim": (C.c_int, [C.c_void_p]),
+    "fdnn_model_hidden_dim": (C.c_int, [C.c_void_p]),
+    "fdnn_model_layer_count": (C.c_int, [C.c_void_p]),
+    "fdnn_model_layer_dim": (C.c_int, [C.c_void_p, C.c_int]),
+    "fdnn_model_device": (C.c_int, [C.c_void_p]),
+    "fdnn_model_set_l0_fma": (C.c_int, [C.c_void_p, C.c_int]),
+    "fdnn_calculate": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, C.c_int, _c_f32p]),
+    "fdnn_calculate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "fdnn_ctx_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "fdnn_ctx_free": (None, [C.c_void_p]),
+    "fdnn_ctx_frame_count": (C.c_int, [C.c_void_p]),
+    "fdnn_ctx_output_dim": (C.c_int, [C.c_void_p]),
+    "fdnn_ctx_forward_hidden": (C.c_int, [C.c_void_p, _c_f32p]),
+    "fdnn_ctx_forward_hidden_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fdnn_ctx_lazy_output": (C.c_int, [C.c_void_p, C.c_int, _c_i8p, _c_f32p]),
+    "fdnn_ctx_lazy_output_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_i8p, _c_f32p]),
+    "fdnn_ctx_lazy_output_batch_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fdnn_ctx_output": (C.c_int, [C.c_void_p, _c_f32p]),
+    "fdnn_ctx_output_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "fdnn_ctx_read_hidden": (C.c_int, [C.c_void_p, _c_u8p]),
+    "fdnn_model_blob_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "fdnn_model_export_blob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "fdnn_model_import_blob": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "fdnn_debug_forward_taps": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_i8p, _c_f32p, _c_u8p, _c_i32p, _c_i32p, _c_f32p, _c_f32p]),
+    "fdnn_profile_begin": (C.c_int, [C.c_void_p]),
+    "fdnn_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "fdnn_host_model_load": (C.c_int, [C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),
+    "fdnn_host_model_free": (None, [C.c_void_p]),
+    "fdnn_host_model_layers": (C.c_int, [C.c_void_p]),
+    "fdnn_host_model_layer_in": (C.c_int, [C.c_void_p, C.c_int]),
+    "fdnn_host_model_layer_out": (C.c_int, [C.c_void_p, C.c_int]),
+    "fdnn_host_model_multiplier": (C.c_float, [C.c_void_p, C.c_int]),
+    "fdnn_host_model_weights_q": (C.c_int, [C.c_void_p, C.c_int, _c_i8p]),
+    "fdnn_host_model_bias": (C.c_int, [C.c_void_p, C.c_int, _c_f32p]),
+    "fdnn_host_model_wsum128": (C.c_int, [C.c_void_p, C.c_int, _c_i32p]),
+    "fdnn_host_model_risky_pairs": (C.c_longlong, [C.c_void_p, C.c_int]),
+    "fdnn_host_model_blob_size": (C.c_size_t, [C.c_void_p]),
+    "fdnn_host_model_blob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "fdnn_host_blob_check": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int)]),
+    "fdnn_host_sigmoid_lut": (C.c_int, [_c_u8p]),
+    "fdnn_host_quantize": (C.c_int, [_c_f32p, C.c_int, C.c_int, C.c_float, _c_i8p, _c_f32p]),
+}
+
+JNI_SYMBOLS = [
+    "Java_suskun_nn_QuantizedDnn_" + n
+    for n in ("initialize", "inputDimension", "outputDimension", "calculate", "getContext", "calculateUntilOutput",
+              "calculateLazy", "deleteLazyContext", "delete", "layerDimension", "layerCount")
+]
+
+
+def lib() -> C.CDLL:
+    """Load libfast-dnn.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback for the scorer)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != FDNN_OK:
+        raise FdnnError(rc, lib().fdnn_last_error().decode(errors="replace"))
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def device_count() -> int:
+    return int(lib().fdnn_device_count())
+
+
+class LazyContext:
+    """``QuantizedDnn.LazyContext`` (QuantizedDnn.java:72-98)."""
+
+    def __init__(self, dnn: "QuantizedDnn", handle: int, input_vector_count: int):
+        self.dnn = dnn
+        self.handle = handle
+        self.inputVectorCount = input_vector_count
+        self.currentVectorIndex = 0
+
+    def calculateUntilOutput(self, input) -> None:
+        x = _f32(input)
+        if x.shape != (self.inputVectorCount, self.dnn.inputDimension()):
+            raise ValueError(f"expected {self.inputVectorCount}x{self.dnn.inputDimension()} frames, got {x.shape}")
+        _check(lib().fdnn_ctx_forward_hidden(self.handle, x.ctypes.data_as(_c_f32p)))
+
+    def calculateForOutputNodes(self, activeNodesMask) -> np.ndarray:
+        mask = np.ascontiguousarray(activeNodesMask, dtype=np.int8)
+        if mask.shape != (self.dnn.outputDimension(),):
+            raise ValueError("mask length must equal the output dimension")
+        out = np.empty(self.dnn.outputDimension(), dtype=np.float32)
+        _check(lib().fdnn_ctx_lazy_output(self.handle, self.currentVectorIndex, mask.ctypes.data_as(_c_i8p),
+                                          out.ctypes.data_as(_c_f32p)))
+        self.currentVectorIndex += 1
+        return out
+
+    # batched form of the same contract
+    def calculateForOutputNodesBatch(self, masks, first: int = 0) -> np.ndarray:
+        masks = np.ascontiguousarray(masks, dtype=np.int8)
+        count = masks.shape[0]
+        out = np.empty((count, self.dnn.outputDimension()), dtype=np.float32)
+        _check(lib().fdnn_ctx_lazy_output_batch(self.handle, first, count, masks.ctypes.data_as(_c_i8p),
+                                                out.ctypes.data_as(_c_f32p)))
+        return out
+
+    def hiddenActivations(self) -> np.ndarray:
+        out = np.empty((self.inputVectorCount, self.dnn.hiddenDimension()), dtype=np.uint8)
+        _check(lib().fdnn_ctx_read_hidden(self.handle, out.ctypes.data_as(_c_u8p)))
+        return out
+
+    def delete(self) -> None:
+        if self.handle:
+            lib().fdnn_ctx_free(self.handle)
+            self.handle = None
+
+
+class QuantizedDnn:
+    """``suskun.nn.QuantizedDnn`` (QuantizedDnn.java) on one MI355X."""
+
+    def __init__(self, handle: int):
+        self.nativeDnnHandle = handle
+
+    # -- construction ---------------------------------------------------
+    @staticmethod
+    def loadFromFile(dnnFile: str, weightCutOffValue: float = 3.0, device: Optional[int] = None) -> "QuantizedDnn":
+        if weightCutOffValue <= 0:  # QuantizedDnn.java:55-57
+            raise ValueError(f"Weight cut off value must be positive. But it is {weightCutOffValue}")
+        h = C.c_void_p()
+        path = os.path.abspath(dnnFile).encode()
+        if device is None:
+            _check(lib().fdnn_model_load(path, weightCutOffValue, C.byref(h)))
+        else:
+            _check(lib().fdnn_model_load_on(path, weightCutOffValue, device, C.byref(h)))
+        return QuantizedDnn(h.value)
+
+    @staticmethod
+    def fromDeviceBlob(d_ptr: int, nbytes: int, device: int) -> "QuantizedDnn":
+        h = C.c_void_p()
+        _check(lib().fdnn_model_import_blob(C.c_void_p(d_ptr), nbytes, device, C.byref(h)))
+        return QuantizedDnn(h.value)
+
+    def delete(self) -> None:
+        if self.nativeDnnHandle:
+            lib().fdnn_model_free(self.nativeDnnHandle)
+            self.nativeDnnHandle = None
+
+    # -- queries ----------------------------------------------------------
+    def inputDimension(self) -> int:
+        return lib().fdnn_model_input_dim(self.nativeDnnHandle)
+
+    def outputDimension(self) -> int:
+        return lib().fdnn_model_output_dim(self.nativeDnnHandle)
+
+    def hiddenDimension(self) -> int:
+        return lib().fdnn_model_hidden_dim(self.nativeDnnHandle)
+
+    def layerDimension(self, layerIndex: int) -> int:
+        return lib().fdnn_model_layer_dim(self.nativeDnnHandle, layerIndex)
+
+    def layerCount(self) -> int:
+        return lib().fdnn_model_layer_count(self.nativeDnnHandle)
+
+    def setInputLayerFma(self, on: bool) -> None:
+        _check(lib().fdnn_model_set_l0_fma(self.nativeDnnHandle, int(on)))
+
+    # -- dense path ---------------------------------------------------------
+    def calculate(self, input, batchSize: int = 10) -> np.ndarray:
+        """float[][] calculate(float[][] input, int batchSize) -- QuantizedDnn.java:149-167."""
+        x = np.asarray(input, dtype=np.float32)
+        if x.shape[0] == 0:  # QuantizedDnn.java:154-156
+            return np.zeros((0, 0), dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.inputDimension():
+            raise ValueError(f"Input vector size {x.shape[-1]} must be equal with network input size {self.inputDimension()}")
+        x = np.ascontiguousarray(x)
+        out = np.empty((x.shape[0], self.outputDimension()), dtype=np.float32)
+        _check(lib().fdnn_calculate(self.nativeDnnHandle, x.ctypes.data_as(_c_f32p), x.shape[0], x.shape[1], batchSize,
+                                    out.ctypes.data_as(_c_f32p)))
+        return out
+
+    def calculate_device(self, d_x: int, n: int, d_out: int, stream: int = 0) -> None:
+        """Device-resident form: raw device pointers (e.g. ``tensor.data_ptr()``), enqueued on ``stream``."""
+        _check(lib().fdnn_calculate_device(self.nativeDnnHandle, C.c_void_p(d_x), n, C.c_void_p(d_out), C.c_void_p(stream)))
+
+    # -- lazy path ----------------------------------------------------------
+    def getNewLazyContext(self, inputVectorCount: int, batchSize: int = 8) -> LazyContext:
+        h = C.c_void_p()
+        _check(lib().fdnn_ctx_create(self.nativeDnnHandle, inputVectorCount, batchSize, C.byref(h)))
+        return LazyContext(self, h.value, inputVectorCount)
+
+    # -- weight blob (multi-GPU) -------------------------------------------
+    def blobSize(self) -> int:
+        n = C.c_size_t()
+        _check(lib().fdnn_model_blob_size(self.nativeDnnHandle, C.byref(n)))
+        return int(n.value)
+
+    def exportBlob(self, d_dst: int, capacity: int, stream: int = 0) -> None:
+        _check(lib().fdnn_model_export_blob(self.nativeDnnHandle, C.c_void_p(d_dst), capacity, C.c_void_p(stream)))
+
+    # -- per-kernel HIP-event timing ------------------------------------------
+    PROF_KINDS = ("l0", "fix", "hidden_gemm", "output_gemm", "normalize")
+
+    def profileBegin(self) -> None:
+        _check(lib().fdnn_profile_begin(self.nativeDnnHandle))
+
+    def profileEnd(self) -> dict:
+        ms = (C.c_double * 5)()
+        cnt = (C.c_int * 5)()
+        _check(lib().fdnn_profile_end(self.nativeDnnHandle, ms, cnt))
+        return {k: {"ms": float(ms[i]), "launches": int(cnt[i])} for i, k in enumerate(self.PROF_KINDS)}
+
+    # -- parity taps ----------------------------------------------------------
+    def forwardTaps(self, input, masks=None) -> dict:
+        x = _f32(input)
+        n, H, O = x.shape[0], self.hiddenDimension(), self.outputDimension()
+        nh = self.layerCount() - 1
+        t = dict(
+            l0_lin=np.empty((n, H), dtype=np.float32),
+            u8_acts=np.empty((nh, n, H), dtype=np.uint8),
+            acc_hid=np.empty((nh - 1, n, H), dtype=np.int32),
+            acc_out=np.empty((n, O), dtype=np.int32),
+            logits=np.empty((n, O), dtype=np.float32),
+            probs=np.empty((n, O), dtype=np.float32),
+        )
+        m = None
+        if masks is not None:
+            m = np.ascontiguousarray(masks, dtype=np.int8)
+            assert m.shape == (n, O)
+        _check(lib().fdnn_debug_forward_taps(
+            self.nativeDnnHandle, x.ctypes.data_as(_c_f32p), n, m.ctypes.data_as(_c_i8p) if m is not None else None,
+            t["l0_lin"].ctypes.data_as(_c_f32p), t["u8_acts"].ctypes.data_as(_c_u8p), t["acc_hid"].ctypes.data_as(_c_i32p),
+            t["acc_out"].ctypes.data_as(_c_i32p), t["logits"].ctypes.data_as(_c_f32p), t["probs"].ctypes.data_as(_c_f32p)))
+        return t
+
+
+class HostModel:
+    """Load-time half only (no device): .bin parse + quantizer + packed sections."""
+
+    def __init__(self, path: str, cutoff: float = 3.0):
+        h = C.c_void_p()
+        _check(lib().fdnn_host_model_load(os.path.abspath(path).encode(), cutoff, C.byref(h)))
+        self.h = h.value
+        L = lib()
+        self.n_layers = L.fdnn_host_model_layers(self.h)
+
+    def close(self):
+        if self.h:
+            lib().fdnn_host_model_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def layer_in(self, j):
+        return lib().fdnn_host_model_layer_in(self.h, j)
+
+    def layer_out(self, j):
+        return lib().fdnn_host_model_layer_out(self.h, j)
+
+    def multiplier(self, j) -> float:
+        return float(lib().fdnn_host_model_multiplier(self.h, j))
+
+    def weights_q(self, j) -> np.ndarray:
+        out = np.empty((self.layer_out(j), self.layer_in(j)), dtype=np.int8)
+        _check(lib().fdnn_host_model_weights_q(self.h, j, out.ctypes.data_as(_c_i8p)))
+        return out
+
+    def bias(self, j) -> np.ndarray:
+        out = np.empty(self.layer_out(j), dtype=np.float32)
+        _check(lib().fdnn_host_model_bias(self.h, j, out.ctypes.data_as(_c_f32p)))
+        return out
+
+    def wsum128(self, j) -> np.ndarray:
+        out = np.empty(self.layer_out(j), dtype=np.int32)
+        _check(lib().fdnn_host_model_wsum128(self.h, j, out.ctypes.data_as(_c_i32p)))
+        return out
+
+    def risky_pairs(self, j) -> int:
+        return int(lib().fdnn_host_model_risky_pairs(self.h, j))
+
+    def blob_size(self) -> int:
+        return int(lib().fdnn_host_model_blob_size(self.h))
+
+    def blob(self) -> np.ndarray:
+        out = np.empty(self.blob_size(), dtype=np.uint8)
+        _check(lib().fdnn_host_model_blob(self.h, out.ctypes.data_as(C.c_void_p), out.size))
+        return out
+
+
+def host_blob_check(blob: np.ndarray) -> dict:
+    """Receiver-side validation of a broadcast weight blob (no device needed)."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    d = [C.c_int() for _ in range(4)]
+    _check(lib().fdnn_host_blob_check(blob.ctypes.data_as(C.c_void_p), blob.size, *[C.byref(v) for v in d]))
+    return dict(zip(("input_dim", "hidden_dim", "output_dim", "n_affine"), (int(v.value) for v in d)))
+
+
+def host_sigmoid_lut() -> np.ndarray:
+    out = np.empty(1280, dtype=np.uint8)
+    _check(lib().fdnn_host_sigmoid_lut(out.ctypes.data_as(_c_u8p)))
+    return out
+
+
+def host_quantize(w, cutoff: float = 3.0):
+    w = _f32(w)
+    out = np.empty(w.shape, dtype=np.int8)
+    mult = C.c_float()
+    _check(lib().fdnn_host_quantize(w.ctypes.data_as(_c_f32p), w.shape[0], w.shape[1], cutoff, out.ctypes.data_as(_c_i8p),
+                                    C.byref(mult)))
+    return out, float(mult.value)

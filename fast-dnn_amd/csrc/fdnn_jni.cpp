@@ -1,0 +1,143 @@
+// fdnn_jni.cpp -- Java_suskun_nn_QuantizedDnn_* over the C-ABI (include/fdnn.h).
+//
+// Drop-in for the reference shim src/cpp/jni_dnn.cc: same symbols, same argument
+// meaning, same ownership (handles are raw pointers in a jlong, freed only by
+// delete()/deleteLazyContext()).  Differences, all on the safe side:
+//   * inputs are treated as const (the reference shifts/scales the pinned Java
+//     array in place and releases it with JNI_ABORT, dnn.cc:175-192);
+//   * a failure throws java.lang.RuntimeException (IllegalArgumentException for
+//     argument errors) with fdnn_last_error() instead of crashing / exit(3)
+//     (float_dnn.cc:171, :185-188).
+#include <cstring>
+#include <vector>
+
+#include "../../include/fdnn.h"
+#include "../../include/fdnn_jni.h"
+
+namespace {
+
+template <typename Fn>
+inline Fn slot(JNIEnv *env, int index) {
+  return reinterpret_cast<Fn>(const_cast<void *>(env->functions[index]));
+}
+
+using FindClassFn = jclass (*)(JNIEnv *, const char *);
+using ThrowNewFn = jint (*)(JNIEnv *, jclass, const char *);
+using GetStringUTFCharsFn = const char *(*)(JNIEnv *, jstring, jboolean *);
+using ReleaseStringUTFCharsFn = void (*)(JNIEnv *, jstring, const char *);
+using GetArrayLengthFn = jsize (*)(JNIEnv *, jarray);
+using NewFloatArrayFn = jfloatArray (*)(JNIEnv *, jsize);
+using GetByteArrayElementsFn = jbyte *(*)(JNIEnv *, jbyteArray, jboolean *);
+using GetFloatArrayElementsFn = jfloat *(*)(JNIEnv *, jfloatArray, jboolean *);
+using ReleaseByteArrayElementsFn = void (*)(JNIEnv *, jbyteArray, jbyte *, jint);
+using ReleaseFloatArrayElementsFn = void (*)(JNIEnv *, jfloatArray, jfloat *, jint);
+using SetFloatArrayRegionFn = void (*)(JNIEnv *, jfloatArray, jsize, jsize, const jfloat *);
+
+void throw_status(JNIEnv *env, int rc) {
+  const char *cls_name = rc == FDNN_E_ARG ? "java/lang/IllegalArgumentException" : "java/lang/RuntimeException";
+  auto find = slot<FindClassFn>(env, FDNN_JNI_FindClass);
+  auto thr = slot<ThrowNewFn>(env, FDNN_JNI_ThrowNew);
+  if (!find || !thr) return;
+  jclass cls = find(env, cls_name);
+  if (cls) thr(env, cls, fdnn_last_error());
+}
+
+jfloatArray to_java(JNIEnv *env, const float *data, size_t len) {
+  jfloatArray result = slot<NewFloatArrayFn>(env, FDNN_JNI_NewFloatArray)(env, static_cast<jsize>(len));
+  if (result) slot<SetFloatArrayRegionFn>(env, FDNN_JNI_SetFloatArrayRegion)(env, result, 0, static_cast<jsize>(len), data);
+  return result;
+}
+
+}  // namespace
+
+extern "C" {
+
+jlong Java_suskun_nn_QuantizedDnn_initialize(JNIEnv *env, jobject, jstring path, jfloat cutoff) {
+  const char *chars = slot<GetStringUTFCharsFn>(env, FDNN_JNI_GetStringUTFChars)(env, path, nullptr);
+  fdnn_model *m = nullptr;
+  int rc = fdnn_model_load(chars, cutoff, &m);
+  slot<ReleaseStringUTFCharsFn>(env, FDNN_JNI_ReleaseStringUTFChars)(env, path, chars);
+  if (rc) {
+    throw_status(env, rc);
+    return 0;
+  }
+  return reinterpret_cast<jlong>(m);
+}
+
+jint Java_suskun_nn_QuantizedDnn_inputDimension(JNIEnv *, jobject, jlong handle) {
+  return fdnn_model_input_dim(reinterpret_cast<fdnn_model *>(handle));
+}
+
+jint Java_suskun_nn_QuantizedDnn_outputDimension(JNIEnv *, jobject, jlong handle) {
+  return fdnn_model_output_dim(reinterpret_cast<fdnn_model *>(handle));
+}
+
+jfloatArray Java_suskun_nn_QuantizedDnn_calculate(JNIEnv *env, jobject, jlong handle, jfloatArray flat, jint n, jint dim,
+                                                  jint batch) {
+  fdnn_model *m = reinterpret_cast<fdnn_model *>(handle);
+  jfloat *elements = slot<GetFloatArrayElementsFn>(env, FDNN_JNI_GetFloatArrayElements)(env, flat, nullptr);
+  const size_t len = static_cast<size_t>(n) * static_cast<size_t>(fdnn_model_output_dim(m));
+  std::vector<float> out(len);
+  int rc = fdnn_calculate(m, elements, n, dim, batch, out.data());
+  slot<ReleaseFloatArrayElementsFn>(env, FDNN_JNI_ReleaseFloatArrayElements)(env, flat, elements, FDNN_JNI_ABORT);
+  if (rc) {
+    throw_status(env, rc);
+    return nullptr;
+  }
+  return to_java(env, out.data(), len);
+}
+
+jlong Java_suskun_nn_QuantizedDnn_getContext(JNIEnv *env, jobject, jlong handle, jint n, jint batch) {
+  fdnn_ctx *c = nullptr;
+  int rc = fdnn_ctx_create(reinterpret_cast<fdnn_model *>(handle), n, batch, &c);
+  if (rc) {
+    throw_status(env, rc);
+    return 0;
+  }
+  return reinterpret_cast<jlong>(c);
+}
+
+void Java_suskun_nn_QuantizedDnn_calculateUntilOutput(JNIEnv *env, jobject, jlong handle, jfloatArray input) {
+  fdnn_ctx *c = reinterpret_cast<fdnn_ctx *>(handle);
+  jfloat *elements = slot<GetFloatArrayElementsFn>(env, FDNN_JNI_GetFloatArrayElements)(env, input, nullptr);
+  int rc = fdnn_ctx_forward_hidden(c, elements);
+  slot<ReleaseFloatArrayElementsFn>(env, FDNN_JNI_ReleaseFloatArrayElements)(env, input, elements, FDNN_JNI_ABORT);
+  if (rc) throw_status(env, rc);
+}
+
+jfloatArray Java_suskun_nn_QuantizedDnn_calculateLazy(JNIEnv *env, jobject, jlong handle, jint index, jbyteArray mask) {
+  fdnn_ctx *c = reinterpret_cast<fdnn_ctx *>(handle);
+  jbyte *bytes = slot<GetByteArrayElementsFn>(env, FDNN_JNI_GetByteArrayElements)(env, mask, nullptr);
+  // the reference sizes the result by the mask length (jni_dnn.cc:111-113)
+  const jsize len = slot<GetArrayLengthFn>(env, FDNN_JNI_GetArrayLength)(env, mask);
+  std::vector<float> out(static_cast<size_t>(len));
+  int rc = FDNN_E_ARG;
+  if (len == fdnn_ctx_output_dim(c))
+    rc = fdnn_ctx_lazy_output(c, index, bytes, out.data());
+  else
+    fdnn_ctx_lazy_output(c, -1, nullptr, nullptr);  // sets the argument-error text
+  slot<ReleaseByteArrayElementsFn>(env, FDNN_JNI_ReleaseByteArrayElements)(env, mask, bytes, FDNN_JNI_ABORT);
+  if (rc) {
+    throw_status(env, rc);
+    return nullptr;
+  }
+  return to_java(env, out.data(), out.size());
+}
+
+void Java_suskun_nn_QuantizedDnn_deleteLazyContext(JNIEnv *, jobject, jlong handle) {
+  fdnn_ctx_free(reinterpret_cast<fdnn_ctx *>(handle));
+}
+
+void Java_suskun_nn_QuantizedDnn_delete(JNIEnv *, jobject, jlong handle) {
+  fdnn_model_free(reinterpret_cast<fdnn_model *>(handle));
+}
+
+jint Java_suskun_nn_QuantizedDnn_layerDimension(JNIEnv *, jobject, jlong handle, jint index) {
+  return fdnn_model_layer_dim(reinterpret_cast<fdnn_model *>(handle), index);
+}
+
+jint Java_suskun_nn_QuantizedDnn_layerCount(JNIEnv *, jobject, jlong handle) {
+  return fdnn_model_layer_count(reinterpret_cast<fdnn_model *>(handle));
+}
+
+}  // extern "C"

@@ -1,0 +1,340 @@
+// fdnn_model.cpp -- .bin loader, quantizer and weight-blob packer (host only).
+#include "fdnn_model.hpp"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+#include "../../include/fdnn.h"
+
+namespace fdnn {
+
+namespace {
+
+inline uint32_t load_be32(const uint8_t *p) {
+  return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | uint32_t(p[3]);
+}
+
+struct Cursor {
+  const std::vector<uint8_t> &buf;
+  size_t off = 0;
+  bool ok = true;
+  bool need(size_t n) {
+    if (off + n > buf.size()) ok = false;
+    return ok;
+  }
+  int32_t i32() {
+    if (!need(4)) return 0;
+    uint32_t v = load_be32(&buf[off]);
+    off += 4;
+    return int32_t(v);
+  }
+  // n big-endian floats into dst
+  void f32(float *dst, size_t n) {
+    if (!need(4 * n)) return;
+    const uint8_t *p = &buf[off];
+    for (size_t i = 0; i < n; ++i, p += 4) {
+      uint32_t v = load_be32(p);
+      std::memcpy(&dst[i], &v, 4);
+    }
+    off += 4 * n;
+  }
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// static_cast<char>(float) as the reference's x86 build executes it
+// (cvttss2si to int32, "integer indefinite" 0x80000000 when NaN / out of
+// range, low byte kept) -- dnn.cc:499.
+inline int8_t float_to_char_x86(float v) {
+  int32_t i;
+  if (!(v > -2147483904.0f && v < 2147483648.0f))
+    i = std::numeric_limits<int32_t>::min();
+  else
+    i = static_cast<int32_t>(v);
+  return static_cast<int8_t>(static_cast<uint8_t>(i & 0xff));
+}
+
+// RN(1/c) for a positive finite float c.
+float rounded_reciprocal(float c) {
+  if (!(c > 0.0f) || std::isinf(c)) return 0.0f;
+  float y = static_cast<float>(1.0 / static_cast<double>(c));
+  float best = y;
+  double best_err = std::fabs(std::fma(static_cast<double>(c), static_cast<double>(y), -1.0));
+  const float cand[2] = {std::nextafterf(y, 0.0f), std::nextafterf(y, INFINITY)};
+  for (float t : cand) {
+    double e = std::fabs(std::fma(static_cast<double>(c), static_cast<double>(t), -1.0));
+    if (e < best_err) {
+      best_err = e;
+      best = t;
+    }
+  }
+  return best;
+}
+
+}  // namespace
+
+void build_sigmoid_lut(uint8_t *out) {
+  // dnn.cc:100-115: float k = i/100.0f; sigmoid = 1.0f/(1+exp(-k)) in float
+  // (exp resolves to the float overload); round() is std::round(float).
+  for (int i = -kLutHalf; i < kLutHalf; ++i) {
+    float k = static_cast<float>(i) / 100.0f;
+    float sig = 1.0f / (1.0f + std::exp(-k));
+    out[i + kLutHalf] = static_cast<uint8_t>(std::round(sig * 255.0f));
+  }
+}
+
+void quantize_layer(const float *w, int rows, int cols, float cutoff, int8_t *out, float *multiplier) {
+  const float hi = cutoff, lo = -cutoff;
+  // abs-max over the weights clamped to [-cutoff, cutoff] (dnn.cc:148-160, :468-476)
+  float amax = -FLT_MAX;
+  const size_t total = size_t(rows) * size_t(cols);
+  for (size_t i = 0; i < total; ++i) {
+    float f = w[i];
+    if (f < lo) f = lo;
+    if (f > hi) f = hi;
+    float a = std::fabs(f);
+    if (a > amax) amax = a;
+  }
+  const float mult = std::round(127.0f / amax);  // dnn.cc:98, :479
+  // only the lower clamp is live when quantizing (dnn.cc:492-498)
+  for (size_t i = 0; i < total; ++i) {
+    float f = w[i];
+    if (f < lo) f = lo;
+    out[i] = float_to_char_x86(std::round(f * mult));
+  }
+  *multiplier = mult;
+}
+
+namespace {
+
+struct RawLayer {
+  int in_dim = 0, in_pad = 0, out_dim = 0;
+  std::vector<float> w;  // out_dim x in_pad
+  std::vector<float> bias;
+};
+
+int pack(const std::vector<RawLayer> &layers, const std::vector<float> &shift, const std::vector<float> &scale,
+         int in_dim_file, float cutoff, HostModel *hm, std::string *msg) {
+  const int n_affine = int(layers.size());
+  const int H = layers[0].out_dim;
+  const int D = layers[0].in_pad;
+  const int O = layers.back().out_dim;
+  BlobHeader h{};
+  h.magic = kBlobMagic;
+  h.version = kBlobVersion;
+  h.n_affine = n_affine;
+  h.in_dim_file = in_dim_file;
+  h.in_dim = D;
+  h.hidden = H;
+  h.out_dim = O;
+  h.n_q = n_affine - 1;
+  h.cutoff = cutoff;
+
+  // quantize first: section sizes depend on the fix-up lists
+  struct QTmp {
+    std::vector<int8_t> wq;
+    std::vector<int32_t> wsum, slot, fix_ptr;
+    std::vector<FixEntry> ent;
+    float mult = 0;
+    int cols_pad = 0;
+  };
+  std::vector<QTmp> qt(size_t(h.n_q));
+  for (int qi = 0; qi < h.n_q; ++qi) {
+    const RawLayer &L = layers[size_t(qi) + 1];
+    QTmp &t = qt[size_t(qi)];
+    const int rows = L.out_dim, cols = L.in_pad;
+    const int rows_pad = int(align_up(size_t(rows), kRowPad));
+    const int cols_pad = int(align_up(size_t(cols), kColPad));
+    t.cols_pad = cols_pad;
+    t.wq.assign(size_t(rows_pad) * cols_pad, 0);
+    {
+      std::vector<int8_t> dense(size_t(rows) * cols);
+      quantize_layer(L.w.data(), rows, cols, cutoff, dense.data(), &t.mult);
+      for (int r = 0; r < rows; ++r) std::memcpy(&t.wq[size_t(r) * cols_pad], &dense[size_t(r) * cols], size_t(cols));
+    }
+    t.wsum.assign(size_t(rows_pad), 0);
+    t.slot.assign(size_t(rows_pad), -1);
+    t.fix_ptr.push_back(0);
+    for (int r = 0; r < rows; ++r) {
+      const int8_t *wr = &t.wq[size_t(r) * cols_pad];
+      int32_t s = 0;
+      bool any = false;
+      for (int k = 0; k < cols; k += 2) {
+        const int w0 = wr[k], w1 = wr[k + 1];
+        s += w0 + w1;
+        const int pos = (w0 > 0 ? w0 : 0) + (w1 > 0 ? w1 : 0);
+        const int neg = (w0 < 0 ? w0 : 0) + (w1 < 0 ? w1 : 0);
+        if (255 * pos > 32767 || 255 * neg < -32768) {
+          t.ent.push_back(FixEntry{uint16_t(k), int8_t(w0), int8_t(w1)});
+          any = true;
+        }
+      }
+      t.wsum[size_t(r)] = 128 * s;
+      if (any) {
+        t.slot[size_t(r)] = int32_t(t.fix_ptr.size()) - 1;
+        t.fix_ptr.push_back(int32_t(t.ent.size()));
+      }
+    }
+  }
+
+  size_t off = align_up(sizeof(BlobHeader), 256);
+  auto place = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return uint64_t(o);
+  };
+  h.off_w0 = place(sizeof(float) * size_t(H) * D);
+  h.off_b0 = place(sizeof(float) * size_t(H));
+  h.off_shift = place(sizeof(float) * size_t(D));
+  h.off_scale = place(sizeof(float) * size_t(D));
+  h.off_lut = place(size_t(kLutExt) + 15);
+  for (int qi = 0; qi < h.n_q; ++qi) {
+    const RawLayer &L = layers[size_t(qi) + 1];
+    QTmp &t = qt[size_t(qi)];
+    QLayerDesc &d = h.q[qi];
+    d.rows = L.out_dim;
+    d.cols = L.in_pad;
+    d.cols_pad = t.cols_pad;
+    d.rows_pad = int32_t(t.wsum.size());
+    d.n_slots = int32_t(t.fix_ptr.size()) - 1;
+    d.n_fix = int32_t(t.ent.size());
+    d.mult = t.mult;
+    d.coef = t.mult * 255.0f;
+    d.rcp_coef = rounded_reciprocal(d.coef);
+    d.fastdiv_ok = 0;
+    d.off_w = place(t.wq.size());
+    d.off_bias = place(sizeof(float) * size_t(d.rows_pad));
+    d.off_wsum = place(sizeof(int32_t) * size_t(d.rows_pad));
+    d.off_slot = place(sizeof(int32_t) * size_t(d.rows_pad));
+    d.off_fix_ptr = place(sizeof(int32_t) * t.fix_ptr.size());
+    d.off_fix_ent = place(sizeof(FixEntry) * (t.ent.size() + 1));
+  }
+  h.total_bytes = off;
+
+  hm->blob.assign(off, 0);
+  uint8_t *b = hm->blob.data();
+  std::memcpy(b + h.off_w0, layers[0].w.data(), sizeof(float) * size_t(H) * D);
+  std::memcpy(b + h.off_b0, layers[0].bias.data(), sizeof(float) * size_t(H));
+  std::memcpy(b + h.off_shift, shift.data(), sizeof(float) * size_t(D));
+  std::memcpy(b + h.off_scale, scale.data(), sizeof(float) * size_t(D));
+  {
+    uint8_t lut[kLutSize];
+    build_sigmoid_lut(lut);
+    uint8_t *ext = b + h.off_lut;
+    // device table, index clamp(k,-640,640)+640: k <= -640 -> 0, k >= 640 -> 255
+    // (dnn.h:38-41); stored XOR 0x80 because activations travel as s8 = u8 - 128.
+    ext[0] = 0 ^ 0x80;
+    for (int i = 1; i < kLutSize; ++i) ext[i] = lut[i] ^ 0x80;
+    ext[kLutSize] = 255 ^ 0x80;
+  }
+  for (int qi = 0; qi < h.n_q; ++qi) {
+    const RawLayer &L = layers[size_t(qi) + 1];
+    const QTmp &t = qt[size_t(qi)];
+    const QLayerDesc &d = h.q[qi];
+    std::memcpy(b + d.off_w, t.wq.data(), t.wq.size());
+    std::memcpy(b + d.off_bias, L.bias.data(), sizeof(float) * size_t(d.rows));
+    std::memcpy(b + d.off_wsum, t.wsum.data(), sizeof(int32_t) * t.wsum.size());
+    std::memcpy(b + d.off_slot, t.slot.data(), sizeof(int32_t) * t.slot.size());
+    std::memcpy(b + d.off_fix_ptr, t.fix_ptr.data(), sizeof(int32_t) * t.fix_ptr.size());
+    if (!t.ent.empty()) std::memcpy(b + d.off_fix_ent, t.ent.data(), sizeof(FixEntry) * t.ent.size());
+  }
+  std::memcpy(b, &h, sizeof(h));
+  hm->hdr = h;
+  (void)msg;
+  return FDNN_OK;
+}
+
+}  // namespace
+
+int load_host_model(const std::string &path, float cutoff, HostModel *out, std::string *msg) {
+  if (!(cutoff > 0.0f)) {  // QuantizedDnn.java:55-57
+    *msg = "weight cut-off must be positive";
+    return FDNN_E_ARG;
+  }
+  FILE *fp = std::fopen(path.c_str(), "rb");
+  if (!fp) {
+    *msg = "cannot open model file " + path;
+    return FDNN_E_IO;
+  }
+  std::fseek(fp, 0, SEEK_END);
+  long sz = std::ftell(fp);
+  std::rewind(fp);
+  std::vector<uint8_t> buf(sz > 0 ? size_t(sz) : 0);
+  size_t got = buf.empty() ? 0 : std::fread(buf.data(), 1, buf.size(), fp);
+  std::fclose(fp);
+  if (got != buf.size() || buf.size() < 4) {
+    *msg = "short read on " + path;
+    return FDNN_E_IO;
+  }
+  Cursor c{buf};
+  const int n_affine = c.i32();
+  if (n_affine < 4 || n_affine > kMaxQLayers + 1) {
+    // dnn.cc:199 takes hidden_node_count_ from layers()[1]: that must be a hidden layer
+    *msg = "model has " + std::to_string(n_affine) + " affine layers; need 4.." + std::to_string(kMaxQLayers + 1);
+    return FDNN_E_FORMAT;
+  }
+  std::vector<RawLayer> layers(static_cast<size_t>(n_affine));
+  int in_dim_file = 0;
+  for (int j = 0; j < n_affine; ++j) {
+    RawLayer &L = layers[size_t(j)];
+    L.in_dim = c.i32();
+    L.out_dim = c.i32();
+    if (!c.ok || L.in_dim <= 0 || L.out_dim <= 0 || L.in_dim > (1 << 20) || L.out_dim > (1 << 24)) {
+      *msg = "bad layer header at layer " + std::to_string(j);
+      return FDNN_E_FORMAT;
+    }
+    if (j == 0) in_dim_file = L.in_dim;
+    L.in_pad = j == 0 ? int(align_up(size_t(L.in_dim), 4)) : L.in_dim;  // float_dnn.cc:32-33
+    if (!c.need(4 * (size_t(L.in_dim) * L.out_dim + size_t(L.out_dim)))) break;
+    L.w.assign(size_t(L.out_dim) * L.in_pad, 0.0f);
+    for (int o = 0; o < L.out_dim; ++o) c.f32(&L.w[size_t(o) * L.in_pad], size_t(L.in_dim));
+    L.bias.resize(size_t(L.out_dim));
+    c.f32(L.bias.data(), size_t(L.out_dim));
+  }
+  std::vector<float> shift(size_t(layers[0].in_pad), 0.0f), scale(size_t(layers[0].in_pad), 0.0f);
+  c.f32(shift.data(), size_t(in_dim_file));  // zero padded, float_dnn.cc:60-66
+  c.f32(scale.data(), size_t(in_dim_file));
+  if (!c.ok) {
+    *msg = "model file truncated: " + path;
+    return FDNN_E_FORMAT;
+  }
+  const int H = layers[0].out_dim;
+  if (H % 16) {
+    *msg = "hidden width must be a multiple of 16 (README.md:10)";
+    return FDNN_E_FORMAT;
+  }
+  for (int j = 1; j < n_affine; ++j) {
+    const RawLayer &L = layers[size_t(j)];
+    if (L.in_dim != H || (j < n_affine - 1 && L.out_dim != H)) {
+      *msg = "all hidden layers must have the same width (dnn.cc:199-208)";
+      return FDNN_E_FORMAT;
+    }
+  }
+  if (H > 32768) {
+    *msg = "hidden width above 32768 overflows the int32 accumulator bound";
+    return FDNN_E_FORMAT;
+  }
+  return pack(layers, shift, scale, in_dim_file, cutoff, out, msg);
+}
+
+int adopt_blob(std::vector<uint8_t> &&bytes, HostModel *out, std::string *msg) {
+  if (bytes.size() < sizeof(BlobHeader)) {
+    *msg = "blob smaller than its header";
+    return FDNN_E_FORMAT;
+  }
+  BlobHeader h;
+  std::memcpy(&h, bytes.data(), sizeof(h));
+  if (h.magic != kBlobMagic || h.version != kBlobVersion || h.total_bytes != bytes.size() || h.n_q < 3 ||
+      h.n_q > kMaxQLayers) {
+    *msg = "not a fast-dnn weight blob (magic/version/size mismatch)";
+    return FDNN_E_FORMAT;
+  }
+  out->hdr = h;
+  out->blob = std::move(bytes);
+  return FDNN_OK;
+}
+
+}  // namespace fdnn

@@ -1,0 +1,860 @@
+// fdnn_runtime.cpp -- device model, calculation contexts and the C-ABI (include/fdnn.h).
+//
+// Host-side counterpart of the reference's QuantizedDnn (dnn.h:106-142) and
+// CalculationContext (dnn.h:144-208, dnn.cc:194-215, :402-454), re-designed for
+// one MI355X: the model is one immutable packed blob in HBM; a context is a set
+// of persistent device scratch buffers sized for n frames plus its own stream;
+// fdnn_calculate draws contexts from a per-model pool so that concurrent callers
+// (MultiThreadedStressTest.java:48-69) never share scratch.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/fdnn.h"
+#include "fdnn_kernels.hpp"
+#include "fdnn_model.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return fail(FDNN_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+  } while (0)
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct fdnn_host_model {
+  fdnn::HostModel hm;
+};
+
+struct fdnn_model {
+  fdnn::HostModel hm;  // header + host copy of the blob (kept: export, host queries)
+  int device = 0;
+  uint8_t *d_blob = nullptr;
+  int l0_fma = 0;
+  std::mutex mu;
+  std::vector<fdnn_ctx *> pool;  // idle contexts owned by the model (fdnn_calculate*)
+  // per-kernel HIP-event timing (fdnn_profile_begin/end); off in production
+  bool profiling = false;
+  struct ProfRec {
+    int kind;
+    hipEvent_t a, b;
+  };
+  std::vector<ProfRec> prof;
+};
+
+struct fdnn_ctx {
+  fdnn_model *m = nullptr;
+  int n = 0, n_pad = 0;  // frames in use, padded to the GEMM frame tile
+  int cap = 0;            // frames the scratch was allocated for (padded)
+  int act_ld = 0;
+  hipStream_t stream = nullptr;   // own stream for the host-pointer entry points
+  hipEvent_t done = nullptr;      // last enqueued work (pool hand-over between streams)
+  float *d_x = nullptr;           // [n][D]
+  int8_t *d_act[2] = {nullptr, nullptr};  // [n_pad][act_ld] ping/pong, s8 = u8-128
+  float *d_out = nullptr;         // [n][O]
+  float *d_partial = nullptr;     // [rows_pad/64][n_pad]
+  int8_t *d_mask = nullptr;       // [n][O]
+  int32_t *d_corr = nullptr;      // [max n_slots][n_pad]
+  int last = -1;                  // d_act index holding the last hidden layer, -1 = not computed
+  bool pooled = false;
+};
+
+namespace {
+
+using fdnn::BlobHeader;
+using fdnn::QLayerDesc;
+
+struct DeviceGuard {
+  int prev = 0;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+  }
+  ~DeviceGuard() {
+    if (ok) hipSetDevice(prev);
+  }
+};
+
+int upload_model(fdnn_model *m) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(FDNN_E_DEVICE, "no HIP device available: this library has no CPU path");
+  if (m->device < 0 || m->device >= count) return fail(FDNN_E_ARG, "device index out of range");
+  DeviceGuard g(m->device);
+  if (!g.ok) return fail(FDNN_E_DEVICE, "hipSetDevice failed");
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_blob), m->hm.blob.size()));
+  // exhaustive validation of the 3-op division per layer (see dequant() in fdnn_kernels.hip)
+  unsigned long long *d_bad = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_bad), sizeof(unsigned long long) * fdnn::kMaxQLayers));
+  HIP_TRY(hipMemset(d_bad, 0, sizeof(unsigned long long) * fdnn::kMaxQLayers));
+  BlobHeader &h = m->hm.hdr;
+  for (int qi = 0; qi < h.n_q; ++qi) {
+    // same coefficient as an earlier layer -> same verdict, skip the sweep
+    int same = -1;
+    for (int pj = 0; pj < qi; ++pj)
+      if (h.q[pj].coef == h.q[qi].coef) same = pj;
+    if (same >= 0) continue;
+    fdnn::launch_fastdiv_check(h.q[qi].coef, h.q[qi].rcp_coef, d_bad + qi, nullptr);
+  }
+  unsigned long long bad[fdnn::kMaxQLayers];
+  HIP_TRY(hipMemcpy(bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost));
+  HIP_TRY(hipFree(d_bad));
+  for (int qi = 0; qi < h.n_q; ++qi) {
+    int src = qi;
+    for (int pj = 0; pj < qi; ++pj)
+      if (h.q[pj].coef == h.q[qi].coef) {
+        src = pj;
+        break;
+      }
+    h.q[qi].fastdiv_ok = (bad[src] == 0) ? 1 : 0;
+  }
+  std::memcpy(m->hm.blob.data(), &h, sizeof(h));
+  HIP_TRY(hipMemcpy(m->d_blob, m->hm.blob.data(), m->hm.blob.size(), hipMemcpyHostToDevice));
+  return FDNN_OK;
+}
+
+void destroy_ctx(fdnn_ctx *c) {
+  if (!c) return;
+  DeviceGuard g(c->m->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  hipFree(c->d_x);
+  hipFree(c->d_act[0]);
+  hipFree(c->d_act[1]);
+  hipFree(c->d_out);
+  hipFree(c->d_partial);
+  hipFree(c->d_mask);
+  hipFree(c->d_corr);
+  if (c->done) hipEventDestroy(c->done);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int make_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
+  DeviceGuard g(m->device);
+  if (!g.ok) return fail(FDNN_E_DEVICE, "hipSetDevice failed");
+  const BlobHeader &h = m->hm.hdr;
+  fdnn_ctx *c = new fdnn_ctx();
+  c->m = m;
+  c->n = n;
+  c->n_pad = round_up(std::max(n, 1), fdnn::kFrameTile);
+  c->cap = c->n_pad;
+  c->act_ld = round_up(h.hidden, fdnn::kColPad);
+  int max_slots = 0, max_rows_pad = 0;
+  for (int qi = 0; qi < h.n_q; ++qi) {
+    max_slots = std::max(max_slots, h.q[qi].n_slots);
+    max_rows_pad = std::max(max_rows_pad, h.q[qi].rows_pad);
+  }
+  const size_t np = size_t(c->n_pad);
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void **p, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16);
+  };
+  alloc(reinterpret_cast<void **>(&c->d_x), sizeof(float) * np * h.in_dim);
+  // one extra frame tile of slack: an output sub-range may start at any frame and
+  // the GEMM always reads whole 128-frame tiles of activation rows
+  alloc(reinterpret_cast<void **>(&c->d_act[0]), (np + fdnn::kFrameTile) * c->act_ld);
+  alloc(reinterpret_cast<void **>(&c->d_act[1]), (np + fdnn::kFrameTile) * c->act_ld);
+  alloc(reinterpret_cast<void **>(&c->d_out), sizeof(float) * np * h.out_dim);
+  alloc(reinterpret_cast<void **>(&c->d_partial), sizeof(float) * np * (max_rows_pad / fdnn::kPartialNodes));
+  alloc(reinterpret_cast<void **>(&c->d_mask), np * h.out_dim);
+  alloc(reinterpret_cast<void **>(&c->d_corr), sizeof(int32_t) * np * std::max(max_slots, 1));
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+  if (e != hipSuccess) {
+    std::string msg = std::string("context allocation for ") + std::to_string(n) + " frames: " + hipGetErrorString(e);
+    destroy_ctx(c);
+    return fail(e == hipErrorOutOfMemory ? FDNN_E_NOMEM : FDNN_E_DEVICE, msg);
+  }
+  *out = c;
+  return FDNN_OK;
+}
+
+// Brackets one kernel launch with HIP events on the launch stream when profiling is on.
+struct ProfScope {
+  fdnn_model *m;
+  hipStream_t s;
+  int kind;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(fdnn_model *m_, hipStream_t s_, int kind_) : m(m_), s(s_), kind(kind_) {
+    if (!m->profiling) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+      a = b = nullptr;
+      return;
+    }
+    hipEventRecord(a, s);
+  }
+  ~ProfScope() {
+    if (!a) return;
+    hipEventRecord(b, s);
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->prof.push_back({kind, a, b});
+  }
+};
+
+struct Taps {
+  float *l0_lin = nullptr;
+  uint8_t *u8_acts = nullptr;   // device [n_hidden][n][H]
+  int32_t *acc_hid = nullptr;   // device [n_hidden-1][n][H]
+  int32_t *acc_out = nullptr;   // device [n][O]
+  float *logits = nullptr;      // device [n][O]
+};
+
+// one device-side u8 snapshot of the s8 activation buffer (taps only)
+int snapshot_acts(const fdnn_ctx *c, int buf, uint8_t *d_dst, hipStream_t s) {
+  const BlobHeader &h = c->m->hm.hdr;
+  // compact [n_pad][act_ld] -> [n][H] while flipping bit 7
+  if (c->act_ld == h.hidden) {
+    fdnn::launch_xor80(c->d_act[buf], d_dst, size_t(c->n) * h.hidden, s);
+  } else {
+    for (int f = 0; f < c->n; ++f)
+      fdnn::launch_xor80(c->d_act[buf] + size_t(f) * c->act_ld, d_dst + size_t(f) * h.hidden, size_t(h.hidden), s);
+  }
+  return FDNN_OK;
+}
+
+// CalculateUntilLastHiddenLayer (dnn.cc:402-424): layer 0, then every int8
+// hidden layer, layer-major over the whole frame batch.
+int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
+  fdnn_model *m = c->m;
+  const BlobHeader &h = m->hm.hdr;
+  const uint8_t *B = m->d_blob;
+  fdnn::L0Params l0{};
+  l0.x = d_x;
+  l0.shift = reinterpret_cast<const float *>(B + h.off_shift);
+  l0.scale = reinterpret_cast<const float *>(B + h.off_scale);
+  l0.w = reinterpret_cast<const float *>(B + h.off_w0);
+  l0.bias = reinterpret_cast<const float *>(B + h.off_b0);
+  l0.lut = B + h.off_lut;
+  l0.act_out = c->d_act[0];
+  l0.act_ld = c->act_ld;
+  l0.tap_lin = taps ? taps->l0_lin : nullptr;
+  l0.n = c->n;
+  l0.D = h.in_dim;
+  l0.H = h.hidden;
+  l0.fma = m->l0_fma;
+  {
+    ProfScope ps(m, s, FDNN_PROF_L0);
+    fdnn::launch_l0(l0, s);
+  }
+  int cur = 0;
+  if (taps && taps->u8_acts) snapshot_acts(c, cur, taps->u8_acts, s);
+  for (int qi = 0; qi < h.n_q - 1; ++qi) {
+    const QLayerDesc &d = h.q[qi];
+    if (d.n_slots > 0) {
+      fdnn::FixParams fp{};
+      fp.a = c->d_act[cur];
+      fp.fix_ptr = reinterpret_cast<const int32_t *>(B + d.off_fix_ptr);
+      fp.fix_ent = B + d.off_fix_ent;
+      fp.corr = c->d_corr;
+      fp.n_slots = d.n_slots;
+      fp.n = c->n;
+      fp.n_pad = c->n_pad;
+      fp.K = c->act_ld;
+      ProfScope ps(m, s, FDNN_PROF_FIX);
+      fdnn::launch_fix(fp, s);
+    }
+    fdnn::QGemmParams g{};
+    g.w = reinterpret_cast<const int8_t *>(B + d.off_w);
+    g.a = c->d_act[cur];
+    g.bias = reinterpret_cast<const float *>(B + d.off_bias);
+    g.wsum = reinterpret_cast<const int32_t *>(B + d.off_wsum);
+    g.slot = d.n_slots > 0 ? reinterpret_cast<const int32_t *>(B + d.off_slot) : nullptr;
+    g.corr = d.n_slots > 0 ? c->d_corr : nullptr;
+    g.lut = B + h.off_lut;
+    g.rows = d.rows;
+    g.rows_pad = d.rows_pad;
+    g.K = d.cols_pad;
+    g.n = c->n;
+    g.n_pad = c->n_pad;
+    g.coef = d.coef;
+    g.rcp_coef = d.rcp_coef;
+    g.fastdiv = d.fastdiv_ok;
+    g.act_out = c->d_act[cur ^ 1];
+    g.act_ld = c->act_ld;
+    g.tap_acc = (taps && taps->acc_hid) ? taps->acc_hid + size_t(qi) * c->n * h.hidden : nullptr;
+    {
+      ProfScope ps(m, s, FDNN_PROF_HIDDEN);
+      fdnn::launch_qgemm_hidden(g, s);
+    }
+    cur ^= 1;
+    if (taps && taps->u8_acts) snapshot_acts(c, cur, taps->u8_acts + size_t(qi + 1) * c->n * h.hidden, s);
+  }
+  c->last = cur;
+  HIP_TRY(hipGetLastError());
+  return FDNN_OK;
+}
+
+// CalculateOutput (dnn.cc:428-454) / LazyOutputActivations (dnn.cc:355-392)
+// over frames [first, first+count) of the context's last hidden activations.
+int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out, hipStream_t s, const Taps *taps) {
+  fdnn_model *m = c->m;
+  const BlobHeader &h = m->hm.hdr;
+  const uint8_t *B = m->d_blob;
+  const QLayerDesc &d = h.q[h.n_q - 1];
+  if (c->last < 0) return fail(FDNN_E_STATE, "output requested before the hidden layers were computed");
+  if (first < 0 || count < 0 || first + count > c->n) return fail(FDNN_E_ARG, "frame range outside the context");
+  if (count == 0) return FDNN_OK;
+  const int8_t *act = c->d_act[c->last] + size_t(first) * c->act_ld;
+  // rows [first+count, first+n_pad) are read by the GEMM as padding frames; the
+  // activation buffers carry one tile of slack rows for that.
+  const int n_pad = round_up(count, fdnn::kFrameTile);
+  if (d.n_slots > 0) {
+    fdnn::FixParams fp{};
+    fp.a = act;
+    fp.fix_ptr = reinterpret_cast<const int32_t *>(B + d.off_fix_ptr);
+    fp.fix_ent = B + d.off_fix_ent;
+    fp.corr = c->d_corr;
+    fp.n_slots = d.n_slots;
+    fp.n = count;
+    fp.n_pad = n_pad;
+    fp.K = c->act_ld;
+    ProfScope ps(m, s, FDNN_PROF_FIX);
+    fdnn::launch_fix(fp, s);
+  }
+  fdnn::QGemmParams g{};
+  g.w = reinterpret_cast<const int8_t *>(B + d.off_w);
+  g.a = act;
+  g.bias = reinterpret_cast<const float *>(B + d.off_bias);
+  g.wsum = reinterpret_cast<const int32_t *>(B + d.off_wsum);
+  g.slot = d.n_slots > 0 ? reinterpret_cast<const int32_t *>(B + d.off_slot) : nullptr;
+  g.corr = d.n_slots > 0 ? c->d_corr : nullptr;
+  g.lut = B + h.off_lut;
+  g.rows = d.rows;
+  g.rows_pad = d.rows_pad;
+  g.K = d.cols_pad;
+  g.n = count;
+  g.n_pad = n_pad;
+  g.coef = d.coef;
+  g.rcp_coef = d.rcp_coef;
+  g.fastdiv = d.fastdiv_ok;
+  g.out = d_out;
+  g.partial = c->d_partial;
+  g.mask = d_masks;
+  g.tap_acc = taps ? taps->acc_out : nullptr;
+  g.tap_logit = taps ? taps->logits : nullptr;
+  {
+    ProfScope ps(m, s, FDNN_PROF_OUTPUT);
+    fdnn::launch_qgemm_output(g, s);
+  }
+  {
+    ProfScope ps(m, s, FDNN_PROF_NORMALIZE);
+    fdnn::launch_normalize(d_out, c->d_partial, count, n_pad, d.rows, d.rows_pad / fdnn::kPartialNodes, s);
+  }
+  HIP_TRY(hipGetLastError());
+  return FDNN_OK;
+}
+
+// pool: idle contexts with capacity >= n.  The hand-over event orders a reuse
+// on another stream behind the previous user's kernels.
+int acquire_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
+  fdnn_ctx *c = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    int best = -1;
+    for (size_t i = 0; i < m->pool.size(); ++i)
+      if (m->pool[i]->cap >= n && (best < 0 || m->pool[i]->cap < m->pool[size_t(best)]->cap)) best = int(i);
+    if (best >= 0) {
+      c = m->pool[size_t(best)];
+      m->pool.erase(m->pool.begin() + best);
+    }
+  }
+  if (!c) {
+    int rc = make_ctx(m, n, &c);
+    if (rc) return rc;
+    c->pooled = true;
+  }
+  c->n = n;
+  c->n_pad = round_up(std::max(n, 1), fdnn::kFrameTile);
+  c->last = -1;
+  *out = c;
+  return FDNN_OK;
+}
+
+void release_ctx(fdnn_ctx *c, hipStream_t s) {
+  hipEventRecord(c->done, s);
+  fdnn_model *m = c->m;
+  fdnn_ctx *victim = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->pool.push_back(c);
+    if (m->pool.size() > 8) {  // keep a handful of the largest contexts
+      auto it = std::min_element(m->pool.begin(), m->pool.end(),
+                                 [](const fdnn_ctx *a, const fdnn_ctx *b) { return a->cap < b->cap; });
+      victim = *it;
+      m->pool.erase(it);
+    }
+  }
+  if (victim) {
+    hipEventSynchronize(victim->done);
+    destroy_ctx(victim);
+  }
+}
+
+}  // namespace
+
+// =====================================================================  C-ABI
+extern "C" {
+
+const char *fdnn_last_error(void) { return g_err.c_str(); }
+const char *fdnn_version(void) { return "fast-dnn_amd 0.1 (gfx950)"; }
+
+int fdnn_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count;
+}
+
+int fdnn_model_load_on(const char *path, float cutoff, int device, fdnn_model **out) {
+  if (!path || !out) return fail(FDNN_E_ARG, "null argument");
+  *out = nullptr;
+  fdnn_model *m = new fdnn_model();
+  std::string msg;
+  int rc = fdnn::load_host_model(path, cutoff, &m->hm, &msg);
+  if (rc) {
+    delete m;
+    return fail(rc, msg);
+  }
+  m->device = device;
+  rc = upload_model(m);
+  if (rc) {
+    if (m->d_blob) hipFree(m->d_blob);
+    delete m;
+    return rc;
+  }
+  *out = m;
+  return FDNN_OK;
+}
+
+int fdnn_model_load(const char *path, float cutoff, fdnn_model **out) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  return fdnn_model_load_on(path, cutoff, dev, out);
+}
+
+void fdnn_model_free(fdnn_model *m) {
+  if (!m) return;
+  for (fdnn_ctx *c : m->pool) destroy_ctx(c);
+  m->pool.clear();
+  {
+    DeviceGuard g(m->device);
+    hipFree(m->d_blob);
+  }
+  delete m;
+}
+
+int fdnn_model_input_dim(const fdnn_model *m) { return m ? m->hm.hdr.in_dim : -1; }
+int fdnn_model_output_dim(const fdnn_model *m) { return m ? m->hm.hdr.out_dim : -1; }
+int fdnn_model_hidden_dim(const fdnn_model *m) { return m ? m->hm.hdr.hidden : -1; }
+int fdnn_model_layer_count(const fdnn_model *m) { return m ? m->hm.hdr.n_q + 1 : -1; }  // jni_dnn.cc:155
+int fdnn_model_device(const fdnn_model *m) { return m ? m->device : -1; }
+
+int fdnn_model_layer_dim(const fdnn_model *m, int index) {
+  if (!m) return -1;
+  const BlobHeader &h = m->hm.hdr;
+  if (index < 0) return -1;
+  if (index == 0) return h.hidden;           // input_layer()->node_count(), jni_dnn.cc:144-146
+  if (index >= h.n_q) return -1;             // layers()[index] must exist (see fdnn.h)
+  return h.q[index].rows;                    // layers()[index]->node_count(), jni_dnn.cc:147
+}
+
+int fdnn_model_set_l0_fma(fdnn_model *m, int on) {
+  if (!m) return fail(FDNN_E_ARG, "null model");
+  m->l0_fma = on ? 1 : 0;
+  return FDNN_OK;
+}
+
+// ---------------------------------------------------------------- contexts
+int fdnn_ctx_create(fdnn_model *m, int n, int batch_hint, fdnn_ctx **out) {
+  (void)batch_hint;  // frame blocking is a CPU cache device; results never depend on it
+  if (!m || !out) return fail(FDNN_E_ARG, "null argument");
+  if (n < 0) return fail(FDNN_E_ARG, "negative frame count");
+  return make_ctx(m, n, out);
+}
+
+void fdnn_ctx_free(fdnn_ctx *c) {
+  if (!c) return;
+  destroy_ctx(c);
+}
+
+int fdnn_ctx_frame_count(const fdnn_ctx *c) { return c ? c->n : -1; }
+int fdnn_ctx_output_dim(const fdnn_ctx *c) { return c ? c->m->hm.hdr.out_dim : -1; }
+
+int fdnn_ctx_forward_hidden_device(fdnn_ctx *c, const float *d_x, void *stream) {
+  if (!c || (!d_x && c->n)) return fail(FDNN_E_ARG, "null argument");
+  if (c->n == 0) {
+    c->last = 0;
+    return FDNN_OK;
+  }
+  DeviceGuard g(c->m->device);
+  return run_hidden(c, d_x, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int fdnn_ctx_forward_hidden(fdnn_ctx *c, const float *x) {
+  if (!c || (!x && c->n)) return fail(FDNN_E_ARG, "null argument");
+  if (c->n == 0) {
+    c->last = 0;
+    return FDNN_OK;
+  }
+  DeviceGuard g(c->m->device);
+  const BlobHeader &h = c->m->hm.hdr;
+  HIP_TRY(hipMemcpyAsync(c->d_x, x, sizeof(float) * size_t(c->n) * h.in_dim, hipMemcpyHostToDevice, c->stream));
+  int rc = run_hidden(c, c->d_x, c->stream, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return FDNN_OK;
+}
+
+int fdnn_ctx_lazy_output_batch_device(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out,
+                                      void *stream) {
+  if (!c || !d_out) return fail(FDNN_E_ARG, "null argument");
+  DeviceGuard g(c->m->device);
+  return run_output(c, first, count, d_masks, d_out, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *masks, float *out) {
+  if (!c || !out || !masks) return fail(FDNN_E_ARG, "null argument");
+  if (c->last < 0) return fail(FDNN_E_STATE, "calculateLazy before calculateUntilOutput");
+  if (first < 0 || count < 0 || first + count > c->n) return fail(FDNN_E_ARG, "frame index outside the context");
+  if (count == 0) return FDNN_OK;
+  DeviceGuard g(c->m->device);
+  const BlobHeader &h = c->m->hm.hdr;
+  const size_t O = size_t(h.out_dim);
+  HIP_TRY(hipMemcpyAsync(c->d_mask, masks, size_t(count) * O, hipMemcpyHostToDevice, c->stream));
+  int rc = run_output(c, first, count, c->d_mask, c->d_out, c->stream, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_out, sizeof(float) * size_t(count) * O, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return FDNN_OK;
+}
+
+int fdnn_ctx_lazy_output(fdnn_ctx *c, int frame, const int8_t *mask, float *out) {
+  return fdnn_ctx_lazy_output_batch(c, frame, 1, mask, out);
+}
+
+int fdnn_ctx_output_device(fdnn_ctx *c, float *d_out, void *stream) {
+  if (!c || !d_out) return fail(FDNN_E_ARG, "null argument");
+  DeviceGuard g(c->m->device);
+  return run_output(c, 0, c->n, nullptr, d_out, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int fdnn_ctx_output(fdnn_ctx *c, float *out) {
+  if (!c || !out) return fail(FDNN_E_ARG, "null argument");
+  if (c->n == 0) return FDNN_OK;
+  DeviceGuard g(c->m->device);
+  int rc = run_output(c, 0, c->n, nullptr, c->d_out, c->stream, nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(out, c->d_out, sizeof(float) * size_t(c->n) * c->m->hm.hdr.out_dim, hipMemcpyDeviceToHost,
+                         c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return FDNN_OK;
+}
+
+int fdnn_ctx_read_hidden(fdnn_ctx *c, uint8_t *out) {
+  if (!c || !out) return fail(FDNN_E_ARG, "null argument");
+  if (c->last < 0) return fail(FDNN_E_STATE, "hidden layers not computed yet");
+  if (c->n == 0) return FDNN_OK;
+  DeviceGuard g(c->m->device);
+  const int H = c->m->hm.hdr.hidden;
+  std::vector<int8_t> tmp(size_t(c->n) * c->act_ld);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpy(tmp.data(), c->d_act[c->last], tmp.size(), hipMemcpyDeviceToHost));
+  for (int f = 0; f < c->n; ++f)
+    for (int i = 0; i < H; ++i) out[size_t(f) * H + i] = uint8_t(tmp[size_t(f) * c->act_ld + i]) ^ 0x80;
+  return FDNN_OK;
+}
+
+// ---------------------------------------------------------------- dense path
+int fdnn_calculate_device(fdnn_model *m, const float *d_x, int n, float *d_out, void *stream) {
+  if (!m || n < 0) return fail(FDNN_E_ARG, "bad argument");
+  if (n == 0) return FDNN_OK;
+  if (!d_x || !d_out) return fail(FDNN_E_ARG, "null buffer");
+  DeviceGuard g(m->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  fdnn_ctx *c = nullptr;
+  int rc = acquire_ctx(m, n, &c);
+  if (rc) return rc;
+  HIP_TRY(hipStreamWaitEvent(s, c->done, 0));
+  rc = run_hidden(c, d_x, s, nullptr);
+  if (!rc) rc = run_output(c, 0, n, nullptr, d_out, s, nullptr);
+  release_ctx(c, s);
+  return rc;
+}
+
+int fdnn_calculate(fdnn_model *m, const float *x, int n, int dim, int batch_hint, float *out) {
+  (void)batch_hint;
+  if (!m || n < 0) return fail(FDNN_E_ARG, "bad argument");
+  if (n == 0) return FDNN_OK;  // QuantizedDnn.java:154-156
+  if (!x || !out) return fail(FDNN_E_ARG, "null buffer");
+  const BlobHeader &h = m->hm.hdr;
+  if (dim != h.in_dim)  // QuantizedDnn.java:157-161
+    return fail(FDNN_E_ARG, "input vector size " + std::to_string(dim) + " must be equal with network input size " +
+                                std::to_string(h.in_dim));
+  DeviceGuard g(m->device);
+  fdnn_ctx *c = nullptr;
+  int rc = acquire_ctx(m, n, &c);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  hipError_t e = hipStreamWaitEvent(s, c->done, 0);
+  if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x, sizeof(float) * size_t(n) * dim, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    rc = run_hidden(c, c->d_x, s, nullptr);
+    if (!rc) rc = run_output(c, 0, n, nullptr, c->d_out, s, nullptr);
+    if (!rc) e = hipMemcpyAsync(out, c->d_out, sizeof(float) * size_t(n) * h.out_dim, hipMemcpyDeviceToHost, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  release_ctx(c, s);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("fdnn_calculate: ") + hipGetErrorString(e));
+  return FDNN_OK;
+}
+
+// ---------------------------------------------------------------- taps
+int fdnn_debug_forward_taps(fdnn_model *m, const float *x, int n, const int8_t *masks, float *l0_lin, uint8_t *u8_acts,
+                            int32_t *acc_hid, int32_t *acc_out, float *logits, float *probs) {
+  if (!m || !x || n <= 0) return fail(FDNN_E_ARG, "bad argument");
+  DeviceGuard g(m->device);
+  const BlobHeader &h = m->hm.hdr;
+  const size_t H = size_t(h.hidden), O = size_t(h.out_dim), N = size_t(n);
+  const int n_hidden = h.n_q;  // fp32 layer + (n_q - 1) int8 hidden layers
+  fdnn_ctx *c = nullptr;
+  int rc = make_ctx(m, n, &c);
+  if (rc) return rc;
+  Taps t{};
+  hipError_t e = hipSuccess;
+  auto alloc = [&](void **p, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(p, bytes);
+  };
+  alloc(reinterpret_cast<void **>(&t.l0_lin), sizeof(float) * N * H);
+  alloc(reinterpret_cast<void **>(&t.u8_acts), size_t(n_hidden) * N * H);
+  alloc(reinterpret_cast<void **>(&t.acc_hid), sizeof(int32_t) * size_t(std::max(n_hidden - 1, 1)) * N * H);
+  alloc(reinterpret_cast<void **>(&t.acc_out), sizeof(int32_t) * N * O);
+  alloc(reinterpret_cast<void **>(&t.logits), sizeof(float) * N * O);
+  hipStream_t s = c->stream;
+  if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x, sizeof(float) * N * h.in_dim, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && masks) e = hipMemcpyAsync(c->d_mask, masks, N * O, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    rc = run_hidden(c, c->d_x, s, &t);
+    if (!rc) rc = run_output(c, 0, n, masks ? c->d_mask : nullptr, c->d_out, s, &t);
+  }
+  auto fetch = [&](void *dst, const void *src, size_t bytes) {
+    if (dst && e == hipSuccess && !rc) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s);
+  };
+  fetch(l0_lin, t.l0_lin, sizeof(float) * N * H);
+  fetch(u8_acts, t.u8_acts, size_t(n_hidden) * N * H);
+  fetch(acc_hid, t.acc_hid, sizeof(int32_t) * size_t(n_hidden - 1) * N * H);
+  fetch(acc_out, t.acc_out, sizeof(int32_t) * N * O);
+  fetch(logits, t.logits, sizeof(float) * N * O);
+  fetch(probs, c->d_out, sizeof(float) * N * O);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(t.l0_lin);
+  hipFree(t.u8_acts);
+  hipFree(t.acc_hid);
+  hipFree(t.acc_out);
+  hipFree(t.logits);
+  fdnn_ctx_free(c);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("taps: ") + hipGetErrorString(e));
+  return FDNN_OK;
+}
+
+// ---------------------------------------------------------------- per-kernel timing
+int fdnn_profile_begin(fdnn_model *m) {
+  if (!m) return fail(FDNN_E_ARG, "null model");
+  std::lock_guard<std::mutex> lk(m->mu);
+  for (auto &r : m->prof) {
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  m->prof.clear();
+  m->profiling = true;
+  return FDNN_OK;
+}
+
+int fdnn_profile_end(fdnn_model *m, double *ms, int *launches) {
+  if (!m || !ms || !launches) return fail(FDNN_E_ARG, "null argument");
+  DeviceGuard g(m->device);
+  std::vector<fdnn_model::ProfRec> recs;
+  {
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->profiling = false;
+    recs.swap(m->prof);
+  }
+  for (int k = 0; k < FDNN_PROF_KINDS; ++k) {
+    ms[k] = 0.0;
+    launches[k] = 0;
+  }
+  int rc = FDNN_OK;
+  for (auto &r : recs) {
+    float t = 0.0f;
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, r.a, r.b);
+    if (e == hipSuccess) {
+      ms[r.kind] += t;
+      launches[r.kind]++;
+    } else {
+      rc = fail(FDNN_E_DEVICE, std::string("profile: ") + hipGetErrorString(e));
+    }
+    hipEventDestroy(r.a);
+    hipEventDestroy(r.b);
+  }
+  return rc;
+}
+
+// ---------------------------------------------------------------- weight blob exchange
+int fdnn_model_blob_size(const fdnn_model *m, size_t *bytes) {
+  if (!m || !bytes) return fail(FDNN_E_ARG, "null argument");
+  *bytes = m->hm.blob.size();
+  return FDNN_OK;
+}
+
+int fdnn_model_export_blob(const fdnn_model *m, void *d_dst, size_t capacity, void *stream) {
+  if (!m || !d_dst) return fail(FDNN_E_ARG, "null argument");
+  if (capacity < m->hm.blob.size()) return fail(FDNN_E_ARG, "destination smaller than the blob");
+  DeviceGuard g(m->device);
+  HIP_TRY(hipMemcpyAsync(d_dst, m->d_blob, m->hm.blob.size(), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return FDNN_OK;
+}
+
+int fdnn_model_import_blob(const void *d_src, size_t bytes, int device, fdnn_model **out) {
+  if (!d_src || !out) return fail(FDNN_E_ARG, "null argument");
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(FDNN_E_DEVICE, "no HIP device available: this library has no CPU path");
+  if (device < 0 || device >= count) return fail(FDNN_E_ARG, "device index out of range");
+  DeviceGuard g(device);
+  std::vector<uint8_t> host(bytes);
+  HIP_TRY(hipMemcpy(host.data(), d_src, bytes, hipMemcpyDeviceToHost));
+  fdnn_model *m = new fdnn_model();
+  std::string msg;
+  int rc = fdnn::adopt_blob(std::move(host), &m->hm, &msg);
+  if (rc) {
+    delete m;
+    return fail(rc, msg);
+  }
+  m->device = device;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&m->d_blob), bytes);
+  if (e == hipSuccess) e = hipMemcpy(m->d_blob, d_src, bytes, hipMemcpyDeviceToDevice);
+  if (e != hipSuccess) {
+    if (m->d_blob) hipFree(m->d_blob);
+    delete m;
+    return fail(FDNN_E_DEVICE, std::string("blob import: ") + hipGetErrorString(e));
+  }
+  *out = m;
+  return FDNN_OK;
+}
+
+// ---------------------------------------------------------------- host-only helpers
+int fdnn_host_model_load(const char *path, float cutoff, fdnn_host_model **out) {
+  if (!path || !out) return fail(FDNN_E_ARG, "null argument");
+  *out = nullptr;
+  fdnn_host_model *hm = new fdnn_host_model();
+  std::string msg;
+  int rc = fdnn::load_host_model(path, cutoff, &hm->hm, &msg);
+  if (rc) {
+    delete hm;
+    return fail(rc, msg);
+  }
+  *out = hm;
+  return FDNN_OK;
+}
+
+void fdnn_host_model_free(fdnn_host_model *hm) { delete hm; }
+int fdnn_host_model_layers(const fdnn_host_model *hm) { return hm ? hm->hm.hdr.n_affine : -1; }
+
+int fdnn_host_model_layer_in(const fdnn_host_model *hm, int j) {
+  if (!hm || j < 0 || j >= hm->hm.hdr.n_affine) return -1;
+  return j == 0 ? hm->hm.hdr.in_dim : hm->hm.hdr.q[j - 1].cols;
+}
+
+int fdnn_host_model_layer_out(const fdnn_host_model *hm, int j) {
+  if (!hm || j < 0 || j >= hm->hm.hdr.n_affine) return -1;
+  return j == 0 ? hm->hm.hdr.hidden : hm->hm.hdr.q[j - 1].rows;
+}
+
+float fdnn_host_model_multiplier(const fdnn_host_model *hm, int j) {
+  if (!hm || j < 1 || j >= hm->hm.hdr.n_affine) return 0.0f;
+  return hm->hm.hdr.q[j - 1].mult;
+}
+
+int fdnn_host_model_weights_q(const fdnn_host_model *hm, int j, int8_t *out) {
+  if (!hm || !out || j < 1 || j >= hm->hm.hdr.n_affine) return fail(FDNN_E_ARG, "bad layer index");
+  const QLayerDesc &d = hm->hm.hdr.q[j - 1];
+  const int8_t *w = hm->hm.wq(j - 1);
+  for (int r = 0; r < d.rows; ++r) std::memcpy(out + size_t(r) * d.cols, w + size_t(r) * d.cols_pad, size_t(d.cols));
+  return FDNN_OK;
+}
+
+int fdnn_host_model_bias(const fdnn_host_model *hm, int j, float *out) {
+  if (!hm || !out || j < 0 || j >= hm->hm.hdr.n_affine) return fail(FDNN_E_ARG, "bad layer index");
+  if (j == 0)
+    std::memcpy(out, hm->hm.b0(), sizeof(float) * size_t(hm->hm.hdr.hidden));
+  else
+    std::memcpy(out, hm->hm.bias(j - 1), sizeof(float) * size_t(hm->hm.hdr.q[j - 1].rows));
+  return FDNN_OK;
+}
+
+int fdnn_host_model_wsum128(const fdnn_host_model *hm, int j, int32_t *out) {
+  if (!hm || !out || j < 1 || j >= hm->hm.hdr.n_affine) return fail(FDNN_E_ARG, "bad layer index");
+  std::memcpy(out, hm->hm.wsum(j - 1), sizeof(int32_t) * size_t(hm->hm.hdr.q[j - 1].rows));
+  return FDNN_OK;
+}
+
+long long fdnn_host_model_risky_pairs(const fdnn_host_model *hm, int j) {
+  if (!hm || j < 1 || j >= hm->hm.hdr.n_affine) return -1;
+  return hm->hm.hdr.q[j - 1].n_fix;
+}
+
+size_t fdnn_host_model_blob_size(const fdnn_host_model *hm) { return hm ? hm->hm.blob.size() : 0; }
+
+int fdnn_host_model_blob(const fdnn_host_model *hm, void *out, size_t capacity) {
+  if (!hm || !out) return fail(FDNN_E_ARG, "null argument");
+  if (capacity < hm->hm.blob.size()) return fail(FDNN_E_ARG, "destination smaller than the blob");
+  std::memcpy(out, hm->hm.blob.data(), hm->hm.blob.size());
+  return FDNN_OK;
+}
+
+int fdnn_host_blob_check(const void *bytes, size_t size, int *input_dim, int *hidden_dim, int *output_dim,
+                         int *n_affine) {
+  if (!bytes) return fail(FDNN_E_ARG, "null argument");
+  std::vector<uint8_t> copy(static_cast<const uint8_t *>(bytes), static_cast<const uint8_t *>(bytes) + size);
+  fdnn::HostModel hm;
+  std::string msg;
+  int rc = fdnn::adopt_blob(std::move(copy), &hm, &msg);
+  if (rc) return fail(rc, msg);
+  if (input_dim) *input_dim = hm.hdr.in_dim;
+  if (hidden_dim) *hidden_dim = hm.hdr.hidden;
+  if (output_dim) *output_dim = hm.hdr.out_dim;
+  if (n_affine) *n_affine = hm.hdr.n_affine;
+  return FDNN_OK;
+}
+
+int fdnn_host_sigmoid_lut(uint8_t *out) {
+  if (!out) return fail(FDNN_E_ARG, "null argument");
+  fdnn::build_sigmoid_lut(out);
+  return FDNN_OK;
+}
+
+int fdnn_host_quantize(const float *w, int rows, int cols, float cutoff, int8_t *out, float *multiplier) {
+  if (!w || !out || !multiplier || rows <= 0 || cols <= 0) return fail(FDNN_E_ARG, "bad argument");
+  fdnn::quantize_layer(w, rows, cols, cutoff, out, multiplier);
+  return FDNN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,194 @@
+/*
+ * fdnn.h -- C-ABI of the MI355X-native fast-dnn scorer (libfast-dnn.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ / torch types.
+ * The JNI exports the Java class suskun.nn.QuantizedDnn binds
+ * (include/fdnn_jni.h) are thin wrappers over these functions, and each entry
+ * point cites the reference interface it replaces (paths relative to the
+ * reference repository).
+ *
+ * Conventions
+ *   - every function returns FDNN_OK (0) or a negative fdnn_status; the text of
+ *     the last error on the calling thread is in fdnn_last_error().
+ *   - "host" pointers are ordinary process memory; "device" pointers (d_*) are
+ *     HIP device memory on the model's device.  Inputs are const: unlike the
+ *     reference (dnn.cc:175-192) the caller's frames are never modified.
+ *   - frames are row-major n x input_dim fp32, input_dim being the padded
+ *     (multiple of 4) layer-0 width the reference reports (jni_dnn.cc:20-25);
+ *     outputs are row-major n x output_dim fp32 soft-max rows.
+ *   - a model handle is immutable after load and may be used from many threads
+ *     at once (jni_dnn.cc:49-51 gives every call its own context; here calls
+ *     draw a device context from a per-model pool).  A context handle is
+ *     single-threaded, like the reference's LazyContext.
+ *   - there is no CPU fallback: without a usable HIP device every entry point
+ *     that computes returns FDNN_E_DEVICE.
+ */
+#ifndef FDNN_H
+#define FDNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDNN_API __attribute__((visibility("default")))
+
+typedef enum fdnn_status {
+  FDNN_OK = 0,
+  FDNN_E_ARG = -1,    /* null / out-of-range argument, dimension mismatch */
+  FDNN_E_IO = -2,     /* file cannot be opened / short read */
+  FDNN_E_FORMAT = -3, /* .bin is not a net this path can run (see fdnn_model_load) */
+  FDNN_E_DEVICE = -4, /* no HIP device, or a HIP call failed */
+  FDNN_E_NOMEM = -5,
+  FDNN_E_STATE = -6   /* call sequence violated (e.g. lazy output before forward_hidden) */
+} fdnn_status;
+
+typedef struct fdnn_model fdnn_model; /* replaces dnn::QuantizedDnn*   (dnn.h:106-142) */
+typedef struct fdnn_ctx fdnn_ctx;     /* replaces dnn::CalculationContext* (dnn.h:144-208) */
+
+FDNN_API const char *fdnn_last_error(void);
+FDNN_API const char *fdnn_version(void);
+FDNN_API int fdnn_device_count(void);
+
+/* ------------------------------------------------------------------ model
+ * fdnn_model_load <- Java initialize(String, float) / jni_dnn.cc:7-18:
+ *   FloatDnn(path) (float_dnn.cc:18-69) + QuantizedDnn(floatDnn, cutoff)
+ *   (dnn.cc:511-531).  Reads the big-endian .bin, pads layer-0 input to x4,
+ *   quantizes layers 1.. with the reference's per-layer multiplier rule
+ *   (dnn.cc:460-509) and uploads one packed weight blob to `device`.
+ *   Accepts what the reference can run: >= 4 affine layers (dnn.cc:199 needs
+ *   layers()[1] to be a hidden layer), all hidden widths equal and x16
+ *   (README.md:10,:69); otherwise FDNN_E_FORMAT.  cutoff must be > 0
+ *   (QuantizedDnn.java:55-57). */
+FDNN_API int fdnn_model_load(const char *path, float cutoff, fdnn_model **out);
+FDNN_API int fdnn_model_load_on(const char *path, float cutoff, int device, fdnn_model **out);
+/* <- Java delete() / jni_dnn.cc:128-133.  Contexts must be freed first. */
+FDNN_API void fdnn_model_free(fdnn_model *m);
+
+/* <- inputDimension / outputDimension / layerCount / layerDimension,
+ *    jni_dnn.cc:20-33, :135-156.  layer_count = quantized layers + 1;
+ *    layer_dim(0) = layer-0 node count, layer_dim(k>=1) = node count of
+ *    quantized layer index k as the reference indexes it (layers()[k], i.e.
+ *    affine layer k+1); out of range -> -1.  The reference reads one past the
+ *    end for k == layer_count-1 (its bound check is off by one); here that
+ *    index returns -1. */
+FDNN_API int fdnn_model_input_dim(const fdnn_model *m);
+FDNN_API int fdnn_model_output_dim(const fdnn_model *m);
+FDNN_API int fdnn_model_hidden_dim(const fdnn_model *m);
+FDNN_API int fdnn_model_layer_count(const fdnn_model *m);
+FDNN_API int fdnn_model_layer_dim(const fdnn_model *m, int index);
+FDNN_API int fdnn_model_device(const fdnn_model *m);
+
+/* Numeric flavour of the fp32 input layer.
+ *   0 (default) -- unfused multiply then add, four k-mod-4 partial sums
+ *                  combined (l0+l1)+(l2+l3): the reference built
+ *                  -O2 -msse4 -ffp-contract=off (dnn.cc:219-247, :168-172).
+ *   1           -- the same chains with fused multiply-add, i.e. the reference
+ *                  built with its own Makefile's -march=native on an FMA host. */
+FDNN_API int fdnn_model_set_l0_fma(fdnn_model *m, int on);
+
+/* ------------------------------------------------------------------ dense path
+ * fdnn_calculate <- Java calculate(long, float[], int, int, int) /
+ *   jni_dnn.cc:35-62 -> CalculationContext::Calculate (dnn.cc:162-165).
+ *   x: host n x dim, out: host n x output_dim.  dim must equal input_dim
+ *   (QuantizedDnn.java:157-161).  n == 0 is a no-op.  batch_hint is the
+ *   reference's frame-block size; results never depend on it. */
+FDNN_API int fdnn_calculate(fdnn_model *m, const float *x, int n, int dim, int batch_hint, float *out);
+/* Same computation on device-resident buffers (the roofline path): d_x and
+ * d_out live on the model's device, work is enqueued on `stream` (a
+ * hipStream_t; NULL = default stream) and NOT synchronized. */
+FDNN_API int fdnn_calculate_device(fdnn_model *m, const float *d_x, int n, float *d_out, void *stream);
+
+/* ------------------------------------------------------------------ contexts / lazy path
+ * fdnn_ctx_create <- getContext / jni_dnn.cc:64-77 (CalculationContext ctor,
+ *   dnn.cc:194-215): device scratch for n frames. */
+FDNN_API int fdnn_ctx_create(fdnn_model *m, int n, int batch_hint, fdnn_ctx **out);
+/* <- deleteLazyContext / jni_dnn.cc:119-126 */
+FDNN_API void fdnn_ctx_free(fdnn_ctx *c);
+FDNN_API int fdnn_ctx_frame_count(const fdnn_ctx *c);
+FDNN_API int fdnn_ctx_output_dim(const fdnn_ctx *c);
+/* <- calculateUntilOutput / jni_dnn.cc:79-95 -> CalculateUntilLastHiddenLayer
+ *    (dnn.cc:402-424).  x: host n x input_dim. */
+FDNN_API int fdnn_ctx_forward_hidden(fdnn_ctx *c, const float *x);
+FDNN_API int fdnn_ctx_forward_hidden_device(fdnn_ctx *c, const float *d_x, void *stream);
+/* <- calculateLazy / jni_dnn.cc:97-117 -> LazyOutputActivations
+ *    (dnn.cc:355-392): one frame, mask of output_dim bytes (non-zero = active).
+ *    Masked-out nodes keep logit 0, contribute exp(0) to the soft-max
+ *    denominator and come back as 1/total.  out: host output_dim floats.
+ *    frame >= n leaves the reference with a partially written buffer; here it
+ *    is FDNN_E_ARG. */
+FDNN_API int fdnn_ctx_lazy_output(fdnn_ctx *c, int frame, const int8_t *mask, float *out);
+/* Batched form of the same contract: frames
+ * [first, first+count) with masks[count][output_dim] -> out[count][output_dim]. */
+FDNN_API int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *masks, float *out);
+FDNN_API int fdnn_ctx_lazy_output_batch_device(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out,
+                                               void *stream);
+/* Dense output layer over the context's hidden activations
+ * (CalculateOutput, dnn.cc:428-454). */
+FDNN_API int fdnn_ctx_output(fdnn_ctx *c, float *out);
+FDNN_API int fdnn_ctx_output_device(fdnn_ctx *c, float *d_out, void *stream);
+/* Last hidden layer's u8 activations, n x hidden_dim (quantized_activations_). */
+FDNN_API int fdnn_ctx_read_hidden(fdnn_ctx *c, uint8_t *out);
+
+/* ------------------------------------------------------------------ multi-GPU weight distribution
+ * Rank 0 quantizes once; the packed blob (header + fp32 layer 0 + int8 layers +
+ * per-node offsets + biases + shift/scale + LUT) is broadcast over RCCL by the
+ * caller and imported on every other device, so all ranks hold bit-identical
+ * weights.  No reference counterpart (the reference is single-process). */
+FDNN_API int fdnn_model_blob_size(const fdnn_model *m, size_t *bytes);
+FDNN_API int fdnn_model_export_blob(const fdnn_model *m, void *d_dst, size_t capacity, void *stream);
+FDNN_API int fdnn_model_import_blob(const void *d_src, size_t bytes, int device, fdnn_model **out);
+
+/* ------------------------------------------------------------------ parity taps (same kernels, extra stores)
+ * Runs the dense path on host buffers and also returns intermediate state;
+ * any output pointer may be NULL.
+ *   l0_lin   [n][H]              layer-0 activation after bias (fp32)
+ *   u8_acts  [n_hidden][n][H]    u8 activations after every hidden layer
+ *   acc_hid  [n_hidden-1][n][H]  int32 accumulators of the int8 hidden layers
+ *                                (pmaddubsw-saturating semantics, dnn.cc:323-349)
+ *   acc_out  [n][O]              same for the output layer
+ *   logits   [n][O]              output value after bias, before soft-max
+ *   probs    [n][O]
+ * masks (may be NULL) switches the output layer to the lazy contract. */
+FDNN_API int fdnn_debug_forward_taps(fdnn_model *m, const float *x, int n, const int8_t *masks, float *l0_lin,
+                                     uint8_t *u8_acts, int32_t *acc_hid, int32_t *acc_out, float *logits, float *probs);
+
+/* ------------------------------------------------------------------ per-kernel timing (bench / profiling only)
+ * Between begin and end every kernel launch of this model is bracketed by HIP
+ * events recorded on the stream it is launched on; end() synchronizes them and
+ * returns the summed device time and launch count per kernel kind. */
+enum { FDNN_PROF_L0 = 0, FDNN_PROF_FIX = 1, FDNN_PROF_HIDDEN = 2, FDNN_PROF_OUTPUT = 3, FDNN_PROF_NORMALIZE = 4, FDNN_PROF_KINDS = 5 };
+FDNN_API int fdnn_profile_begin(fdnn_model *m);
+FDNN_API int fdnn_profile_end(fdnn_model *m, double *ms /*[FDNN_PROF_KINDS]*/, int *launches /*[FDNN_PROF_KINDS]*/);
+
+/* ------------------------------------------------------------------ host-only helpers (no device needed)
+ * The load-time half of the path, exposed so it can be checked on a machine
+ * without a GPU: .bin parsing, the quantizer, the sigmoid table, and the
+ * packed-blob sections the kernels read. */
+typedef struct fdnn_host_model fdnn_host_model;
+FDNN_API int fdnn_host_model_load(const char *path, float cutoff, fdnn_host_model **out);
+FDNN_API void fdnn_host_model_free(fdnn_host_model *hm);
+FDNN_API int fdnn_host_model_layers(const fdnn_host_model *hm); /* affine layers incl. fp32 layer 0 */
+FDNN_API int fdnn_host_model_layer_in(const fdnn_host_model *hm, int j);
+FDNN_API int fdnn_host_model_layer_out(const fdnn_host_model *hm, int j);
+FDNN_API float fdnn_host_model_multiplier(const fdnn_host_model *hm, int j);            /* j >= 1 */
+FDNN_API int fdnn_host_model_weights_q(const fdnn_host_model *hm, int j, int8_t *out);  /* out_dim x in_dim */
+FDNN_API int fdnn_host_model_bias(const fdnn_host_model *hm, int j, float *out);
+FDNN_API int fdnn_host_model_wsum128(const fdnn_host_model *hm, int j, int32_t *out);   /* 128 * sum_k w[node][k] */
+FDNN_API long long fdnn_host_model_risky_pairs(const fdnn_host_model *hm, int j);       /* pairs that can saturate */
+FDNN_API size_t fdnn_host_model_blob_size(const fdnn_host_model *hm);
+/* The packed weight blob as bytes (what fdnn_model_export_blob hands to RCCL),
+ * and the receiver-side validation of such bytes (magic/version/size), with no
+ * device involved -- used by the world_size-2 gloo tests of the load protocol. */
+FDNN_API int fdnn_host_model_blob(const fdnn_host_model *hm, void *out, size_t capacity);
+FDNN_API int fdnn_host_blob_check(const void *bytes, size_t size, int *input_dim, int *hidden_dim, int *output_dim,
+                                  int *n_affine);
+FDNN_API int fdnn_host_sigmoid_lut(uint8_t *out1280); /* QuantizedSigmoid table, dnn.cc:100-115 */
+FDNN_API int fdnn_host_quantize(const float *w, int rows, int cols, float cutoff, int8_t *out, float *multiplier);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDNN_H */

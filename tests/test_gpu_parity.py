@@ -1,0 +1,213 @@
+"""Parity of the HIP path with the CPU oracle and the committed golden vectors.
+All calls go through the C-ABI of libfast-dnn.so (ctypes binding in
+fast_dnn_amd.api).  Integer state is compared bit-for-bit; soft-max
+probabilities to 1e-3 (BASELINE.json north_star), observed ~1e-7."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from fast_dnn_amd import api, formats as F
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3  # north_star tolerance on soft-max probabilities
+TIGHT = 2e-6  # what the implementation actually achieves (expf + sum order)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def x16():
+    return golden("tiny.npz")["x16"]
+
+
+def test_tiny_golden_all_taps(tiny_model_path, x16):
+    g = golden("tiny.npz")
+    dnn = api.QuantizedDnn.loadFromFile(tiny_model_path)
+    assert (dnn.inputDimension(), dnn.outputDimension(), dnn.layerCount()) == (432, 100, 4)
+    assert [dnn.layerDimension(k) for k in range(-1, 5)] == [-1, 64, 64, 100, -1, -1]
+    t = dnn.forwardTaps(x16)
+    assert (t["l0_lin"] == g["l0_lin"]).all()
+    assert (t["u8_acts"] == g["u8_acts"]).all()
+    assert (t["acc_hid"] == g["acc_hid"]).all()
+    assert (t["acc_out"] == g["acc_out"]).all()
+    assert np.abs(t["logits"] - g["logits"]).max() <= 1e-6
+    assert np.abs(t["probs"] - g["probs"]).max() <= TIGHT
+    p = dnn.calculate(x16, 10)
+    assert (p == t["probs"]).all()  # taps run the same kernels
+    p8 = dnn.calculate(g["x8"], 3)
+    assert np.abs(p8 - g["probs8"]).max() <= TIGHT
+    dnn.delete()
+
+
+def test_tiny_fma_flavour(tiny_model_path, x16):
+    g = golden("tiny.npz")
+    dnn = api.QuantizedDnn.loadFromFile(tiny_model_path)
+    dnn.setInputLayerFma(True)
+    t = dnn.forwardTaps(x16)
+    assert (t["l0_lin"] == g["fma_l0_lin"]).all()
+    assert (t["u8_acts"] == g["fma_u8_acts"]).all()
+    assert np.abs(t["probs"] - g["fma_probs"]).max() <= TIGHT
+    dnn.delete()
+
+
+def test_saturation_fixture(sat_model_path):
+    """pmaddubsw pair saturation fires (dnn.cc:337-340): the sparse correction must
+    reproduce the reference's int32 sums exactly."""
+    g = golden("sat.npz")
+    dnn = api.QuantizedDnn.loadFromFile(sat_model_path)
+    t = dnn.forwardTaps(g["x"])
+    assert int(g["sat_events"]) > 0
+    assert (t["u8_acts"] == g["u8_acts"]).all()
+    assert (t["acc_hid"] == g["acc_hid"]).all()
+    assert (t["acc_out"] == g["acc_out"]).all()
+    assert np.abs(t["probs"] - g["probs"]).max() <= TIGHT
+    dnn.delete()
+
+
+def test_mid_lazy_golden(mid_model_path, x16):
+    g = golden("mid_lazy.npz")
+    masks = F.generate_masks(100, 1000, 0.40, 0.03, seed=11)
+    dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+    ctx = dnn.getNewLazyContext(100)  # FuncTest.lazyEmulation protocol (FuncTest.java:92-119)
+    ctx.calculateUntilOutput(x16)
+    assert (ctx.hiddenActivations() == g["hidden_last"]).all()
+    rows = np.stack([ctx.calculateForOutputNodes(masks[i]) for i in range(40)])
+    assert np.abs(rows - g["lazy"]).max() <= TIGHT
+    off = rows[0][masks[0] == 0]
+    assert off.min() > 0 and np.allclose(off, off[0])  # masked-out nodes come back as 1/total
+    batch = ctx.calculateForOutputNodesBatch(masks[:40])
+    assert (batch == rows).all()
+    sub = ctx.calculateForOutputNodesBatch(masks[13:29], first=13)  # unaligned sub-range
+    assert (sub == rows[13:29]).all()
+    ctx.delete()
+    dense = dnn.calculate(x16)
+    assert np.abs(dense[:20] - g["dense"]).max() <= TIGHT
+    dnn.delete()
+
+
+def test_full_net_hashes(net_model_path):
+    g = golden("net_full.npz")
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    assert dnn.layerCount() == 8 and dnn.outputDimension() == 8000
+    t = dnn.forwardTaps(g["x"])
+    assert [sha(t["u8_acts"][j]) for j in range(7)] == list(g["u8_sha256"])
+    assert [sha(t["acc_hid"][j]) for j in range(6)] == list(g["acc_hid_sha256"])
+    assert sha(t["acc_out"]) == str(g["acc_out_sha256"])
+    assert np.abs(t["probs"][:4] - g["probs4"]).max() <= TIGHT
+    dnn.delete()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 127, 128, 129, 300, 1000])
+def test_ragged_batch_sizes_vs_oracle(mid_model_path, n):
+    x = F.synth_features(n, 432, seed=100 + n)
+    dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+    want, wt = Oracle(mid_model_path).calculate(x, taps=True)
+    t = dnn.forwardTaps(x)
+    assert (t["u8_acts"] == wt["u8_acts"]).all()
+    assert (t["acc_hid"] == wt["acc_hid"]).all()
+    assert (t["acc_out"] == wt["acc_out"]).all()
+    assert np.abs(t["probs"] - want).max() <= TIGHT
+    assert np.abs(dnn.calculate(x) - want).max() <= TIGHT
+    dnn.delete()
+
+
+def test_empty_input_and_argument_errors(tiny_model_path):
+    dnn = api.QuantizedDnn.loadFromFile(tiny_model_path)
+    assert dnn.calculate(np.zeros((0, 432), np.float32)).shape == (0, 0)  # QuantizedDnn.java:154-156
+    with pytest.raises(ValueError):
+        dnn.calculate(np.zeros((3, 429), np.float32))  # QuantizedDnn.java:157-161
+    ctx = dnn.getNewLazyContext(4)
+    with pytest.raises(api.FdnnError) as e:
+        ctx.calculateForOutputNodes(np.ones(100, np.int8))  # before calculateUntilOutput
+    assert e.value.code == api.FDNN_E_STATE
+    ctx.calculateUntilOutput(F.synth_features(4))
+    for _ in range(4):
+        ctx.calculateForOutputNodes(np.ones(100, np.int8))
+    with pytest.raises(api.FdnnError) as e:
+        ctx.calculateForOutputNodes(np.ones(100, np.int8))  # frame index past the end
+    assert e.value.code == api.FDNN_E_ARG
+    ctx.delete()
+    dnn.delete()
+
+
+def test_input_is_not_modified(tiny_model_path, x16):
+    """The reference shifts/scales the caller's buffer in place (dnn.cc:175-192); this path must not."""
+    dnn = api.QuantizedDnn.loadFromFile(tiny_model_path)
+    x = x16.copy()
+    dnn.calculate(x)
+    assert (x == x16).all()
+    dnn.delete()
+
+
+def test_nosat_net_has_no_fixups_and_matches(tmp_models):
+    import os
+
+    p = os.path.join(tmp_models, "nosat.bin")
+    F.write_model_bin(p, F.synth_net([432, 256, 256, 256, 500], seed=9, mode="nosat"))
+    hm = api.HostModel(p)
+    assert [hm.risky_pairs(j) for j in range(1, 4)] == [0, 0, 0]
+    x = F.synth_features(200, seed=5)
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    want, wt = Oracle(p).calculate(x, taps=True)
+    t = dnn.forwardTaps(x)
+    assert (t["acc_hid"] == wt["acc_hid"]).all() and (t["acc_out"] == wt["acc_out"]).all()
+    assert np.abs(t["probs"] - want).max() <= TIGHT
+    dnn.delete()
+
+
+def test_masked_dense_equivalences(mid_model_path):
+    """Size-independent properties: all-ones mask == dense; all-zero mask == uniform 1/O."""
+    x = F.synth_features(130, seed=77)
+    dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+    ctx = dnn.getNewLazyContext(130)
+    ctx.calculateUntilOutput(x)
+    ones = ctx.calculateForOutputNodesBatch(np.ones((130, 1000), np.int8))
+    assert (ones == dnn.calculate(x)).all()
+    zeros = ctx.calculateForOutputNodesBatch(np.zeros((130, 1000), np.int8))
+    assert np.allclose(zeros, 1.0 / 1000, rtol=1e-6)
+    ctx.delete()
+    dnn.delete()
+
+
+def test_full_size_properties(net_model_path):
+    """BASELINE config-3 shape (7x2048 -> 8000, 10k frames): soft-max rows sum to 1,
+    results are independent of how the batch is split (frames are independent), and a
+    sample of rows matches the oracle."""
+    x = F.synth_features(10000, seed=21)
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    p = dnn.calculate(x)
+    assert p.shape == (10000, 8000)
+    assert np.abs(p.sum(1, dtype=np.float64) - 1).max() < 1e-4
+    assert (p >= 0).all()
+    head = dnn.calculate(x[:777])
+    assert (head == p[:777]).all()
+    tail = dnn.calculate(x[9000:])
+    assert (tail == p[9000:]).all()
+    idx = np.array([0, 1, 4999, 9998, 9999])
+    want = Oracle(net_model_path).calculate(x[idx])
+    assert np.abs(p[idx] - want).max() <= TIGHT
+    dnn.delete()
+
+
+def test_concurrent_callers_share_one_model(mid_model_path):
+    """MultiThreadedStressTest.java:48-69: many threads, one QuantizedDnn."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+    orc = Oracle(mid_model_path)
+    xs = [F.synth_features(20 + 17 * i, seed=300 + i) for i in range(12)]
+    want = [orc.calculate(x) for x in xs]
+
+    def task(i):
+        return dnn.calculate(xs[i % len(xs)])
+
+    with ThreadPoolExecutor(8) as ex:
+        got = list(ex.map(task, range(96)))
+    for i, gp in enumerate(got):
+        assert np.abs(gp - want[i % len(xs)]).max() <= TIGHT
+    dnn.delete()

@@ -1,0 +1,123 @@
+"""CPU-only checks of the product library: it loads, exports every symbol
+include/*.h declares, its load-time half (loader, quantizer, LUT, per-node
+offsets) matches the golden vectors / oracle, and it refuses to compute without
+a GPU (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+from fast_dnn_amd import api, formats as F
+from oracle.oracle import Oracle
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b(fdnn_[a-z0-9_]+|Java_suskun_nn_QuantizedDnn_[A-Za-z]+)\s*\(", txt))
+
+
+def test_library_exports_every_declared_symbol():
+    L = api.lib()
+    decl = _declared("fdnn.h") | _declared("fdnn_jni.h")
+    assert len(decl) >= 50
+    for name in decl:
+        assert hasattr(L, name), f"{name} declared in include/ but not exported"
+    # and the Python binding covers the whole header
+    assert _declared("fdnn.h") == set(api.SIGNATURES), _declared("fdnn.h") ^ set(api.SIGNATURES)
+    assert _declared("fdnn_jni.h") == set(api.JNI_SYMBOLS)
+
+
+def test_sigmoid_lut_matches_reference_bytes():
+    assert (api.host_sigmoid_lut() == golden("lut.npz")["lut"]).all()
+
+
+def test_quantizer_edge_cases_match_reference():
+    g = golden("quantizer.npz")
+    for name in g["names"]:
+        wq, mult = api.host_quantize(g[f"{name}_w"], float(g[f"{name}_cut"]))
+        assert (wq == g[f"{name}_wq"]).all(), name
+        ref = float(g[f"{name}_mult"])
+        assert mult == ref or (np.isinf(mult) and np.isinf(ref)), name
+
+
+def test_host_model_matches_golden_and_oracle(tiny_model_path):
+    g = golden("tiny.npz")
+    hm = api.HostModel(tiny_model_path)
+    o = Oracle(tiny_model_path)
+    assert hm.n_layers == 4
+    assert [hm.layer_in(j) for j in range(4)] == [432, 64, 64, 64]
+    assert [hm.layer_out(j) for j in range(4)] == [64, 64, 64, 100]
+    wq = np.concatenate([hm.weights_q(j).ravel() for j in range(1, 4)])
+    assert (wq == g["wq"]).all()
+    assert [hm.multiplier(j) for j in range(1, 4)] == list(g["mult"])
+    for j in range(1, 4):
+        assert (hm.bias(j) == o.layer_bias(j)).all()
+        assert (hm.wsum128(j) == 128 * hm.weights_q(j).astype(np.int64).sum(1)).all()
+        assert hm.risky_pairs(j) == o.risky_pairs(j)
+    assert hm.blob_size() % 256 == 0
+
+
+def test_unpadded_input_dim_is_padded_like_the_reference(tmp_path):
+    p = str(tmp_path / "m429.bin")
+    F.write_model_bin(p, F.synth_net([429, 64, 64, 64, 100], seed=2))
+    hm = api.HostModel(p)
+    assert hm.layer_in(0) == 432  # float_dnn.cc:32-33
+    assert Oracle(p).in_dim == 432
+
+
+def test_full_net_quantization_hashes(net_model_path):
+    import hashlib
+
+    g = golden("net_full.npz")
+    hm = api.HostModel(net_model_path)
+    assert [hm.multiplier(j) for j in range(1, hm.n_layers)] == list(g["mult"])
+    sh = [hashlib.sha256(hm.weights_q(j).tobytes()).hexdigest() for j in range(1, hm.n_layers)]
+    assert sh == list(g["wq_sha256"])
+    assert [hm.risky_pairs(j) for j in range(1, hm.n_layers)] == list(g["risky_pairs"])
+
+
+@pytest.mark.parametrize("topo,why", [
+    ([432, 64, 64, 100], "4 affine"),           # dnn.cc:199: layers()[1] must be hidden
+    ([432, 64, 48, 64, 100], "same width"),
+    ([432, 72, 72, 72, 100], "multiple of 16"),
+])
+def test_rejects_nets_the_reference_cannot_run(tmp_path, topo, why):
+    p = str(tmp_path / "bad.bin")
+    F.write_model_bin(p, F.synth_net(topo, seed=1))
+    with pytest.raises(api.FdnnError) as e:
+        api.HostModel(p)
+    assert e.value.code == api.FDNN_E_FORMAT
+
+
+def test_error_paths(tmp_path, tiny_model_path):
+    with pytest.raises(api.FdnnError) as e:
+        api.HostModel(str(tmp_path / "missing.bin"))
+    assert e.value.code == api.FDNN_E_IO
+    trunc = str(tmp_path / "trunc.bin")
+    open(trunc, "wb").write(open(tiny_model_path, "rb").read()[:5000])
+    with pytest.raises(api.FdnnError) as e:
+        api.HostModel(trunc)
+    assert e.value.code == api.FDNN_E_FORMAT
+    with pytest.raises(ValueError):
+        api.QuantizedDnn.loadFromFile(tiny_model_path, weightCutOffValue=0.0)
+
+
+def test_no_cpu_fallback_without_a_gpu(tiny_model_path):
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.FdnnError) as e:
+        api.QuantizedDnn.loadFromFile(tiny_model_path)
+    assert e.value.code == api.FDNN_E_DEVICE and "no CPU path" in str(e.value)
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under fast-dnn_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "fast-dnn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in txt.lower() or f == "__init__.py" and False, os.path.join(dirpath, f)
