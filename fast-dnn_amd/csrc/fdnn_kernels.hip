@@ -7,10 +7,10 @@
 //   ApplyShiftAndScale + InputActivations + AddBias + QuantizedSigmoid
 //     (dnn.cc:175-192, :219-286)                      -> l0_kernel
 //   QuantizedLayerActivations/quantizedNodeSum + AddBias + QuantizedSigmoid
-//     (dnn.cc:289-349, :250-286)                      -> qgemm_kernel<false>
+//     (dnn.cc:289-349, :250-286)                      -> qgemm_kernel<.., OUTPUT=false>
 //   CalculateOutput / LazyOutputActivations + SoftMax
-//     (dnn.cc:428-454, :355-392, :534-544)            -> qgemm_kernel<true> + normalize_kernel
-//   pmaddubsw int16 pair saturation (dnn.cc:337-340)  -> fix_kernel (sparse, exact)
+//     (dnn.cc:428-454, :355-392, :534-544)            -> qgemm_kernel<.., OUTPUT=true> + normalize_kernel
+//   pmaddubsw int16 pair saturation (dnn.cc:337-340)  -> sparse exact correction in the GEMM epilogue
 //
 // u8 x s8 on signed MFMA: activations travel as s8 = u8 - 128 (bit 7 flipped),
 // so sum_k u8*w = sum_k s8*w + 128*sum_k w; the second term is a per-node int32
@@ -69,7 +69,7 @@ constexpr int L0_BK = 16;   // k per LDS chunk
 constexpr int L0_LD = 20;   // padded LDS row (floats): conflict-free ds_read_b128 for rows tx+16j
 
 template <bool FMA, bool TAP>
-__global__ __launch_bounds__(256) void l0_kernel(L0Params p) {
+__global__ __launch_bounds__(256, 4) void l0_kernel(L0Params p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * L0_TF * L0_LD + 2 * L0_TN * L0_LD + (kLutExt + 15) / 4 + 4];
   float *xs = smem;                               // [2][64][20]
   float *ws = smem + 2 * L0_TF * L0_LD;           // [2][64][20]
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void l0_kernel(L0Params p) {
     if (c + 1 < nchunk) gload(c + 1);
     const float *xb = xs + buf * L0_TF * L0_LD;
     const float *wb = ws + buf * L0_TN * L0_LD;
-#pragma unroll
+#pragma unroll 2
     for (int k4 = 0; k4 < L0_BK / 4; ++k4) {
       float4 xv[4], wv[4];
 #pragma unroll
@@ -173,119 +173,213 @@ __global__ __launch_bounds__(256) void l0_kernel(L0Params p) {
 }
 
 // ---------------------------------------------------------------- int8 GEMM (MFMA 32x32x32 i8)
-// Workgroup tile 128 nodes x 128 frames x 128 k, 4 waves as 2 (nodes) x 2
-// (frames), each wave 64x64 = 2x2 MFMA tiles.  Both operands are K-contiguous
-// rows of 128 bytes per k-step, staged HBM->LDS by global_load_lds (16 B/lane,
-// one 8-row slab per wave instruction), double buffered.  LDS rows are 128 B
-// (two rows per 256-B bank row); 16-byte chunk c of row r is stored at chunk
-// c ^ ((r>>1)&7) -- the XOR is applied to the per-lane GLOBAL address while the
-// LDS image stays lane-linear -- which makes every ds_read_b128 fragment read
-// (32 rows x one chunk per half-wave) bank-conflict free.
-constexpr int G_BM = kNodeTile, G_BN = kFrameTile, G_BK = 128;
-constexpr int G_TILE_BYTES = G_BM * G_BK;  // 16 KiB per operand tile
-constexpr int G_LDS_BYTES = 4 * G_TILE_BYTES + ((kLutExt + 15) & ~15);
+// C[node][frame] = sum_k W[node][k] * A[frame][k].  Both operands are
+// K-contiguous byte rows, so both MFMA fragments are plain 16-byte row slices.
+//
+// Workgroup tile: 256 nodes x FT = 32*NF frames, k-step 64 bytes.  4 waves, wave
+// w owns nodes [64w, 64w+64) x all FT frames = 2 x NF MFMA 32x32 tiles
+// (32*NF accumulator registers).  Two workgroups per CU, so one workgroup's
+// VALU epilogue overlaps the other's MFMA main loop.
+//
+// HBM/L2 -> LDS: global_load_lds_dwordx4, one wave instruction = 16 rows x 64 B,
+// into a ring of STAGES buffers; loads stay in flight across the (raw) barrier
+// with a counted s_waitcnt vmcnt, one barrier per k-step.
+//
+// LDS image: rows of 64 B (four rows per 256-B bank row).  16-byte chunk c of row
+// r is stored at chunk c ^ ((r>>2)&3); the XOR is applied to the per-lane GLOBAL
+// address while the LDS destination stays lane-linear, and again on the
+// ds_read_b128 fragment reads, which makes every 16-lane read group hit 16
+// distinct 16-byte slots (conflict free).
+constexpr int G_BM = 256;
+constexpr int G_BK = 64;
+constexpr int G_W_BYTES = G_BM * G_BK;  // 16 KiB
 
-__device__ __forceinline__ void stage_tile(const int8_t *gtile, size_t ld, char *lds_tile, int wave, int lane) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int slab = wave * 4 + j;  // 8 rows each
-    const int r = slab * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    glds16(gtile + static_cast<size_t>(r) * ld + c * 16, lds_tile + slab * 1024);
-  }
+template <int NF>
+struct GemmCfg {
+  static constexpr int FT = 32 * NF;
+  static constexpr int A_BYTES = FT * G_BK;
+  static constexpr int STAGE = G_W_BYTES + A_BYTES;
+  static constexpr int A_SLABS = FT / 16;                 // 1-KiB wave instructions per activation stage
+  static constexpr int MIN_LOADS = 4 + A_SLABS / 4;       // fewest loads any wave issues per stage
+};
+
+template <int NF, int STAGES>
+constexpr int gemm_lds_bytes() {
+  return GemmCfg<NF>::STAGE * STAGES > ((kLutExt + 15) & ~15) ? GemmCfg<NF>::STAGE * STAGES : ((kLutExt + 15) & ~15);
 }
 
 __device__ __forceinline__ v4i read_frag(const char *tile, int row, int chunk) {
-  return *reinterpret_cast<const v4i *>(tile + row * G_BK + ((chunk ^ ((row >> 1) & 7)) << 4));
+  return *reinterpret_cast<const v4i *>(tile + row * G_BK + ((chunk ^ ((row >> 2) & 3)) << 4));
 }
 
-template <bool OUTPUT, bool TAP>
+template <int NF, int STAGES, bool OUTPUT, bool TAP>
 __global__ __launch_bounds__(256, 2) void qgemm_kernel(QGemmParams p) {
+  using Cfg = GemmCfg<NF>;
+  constexpr int FT = Cfg::FT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint8_t *lut = reinterpret_cast<uint8_t *>(smem + 4 * G_TILE_BYTES);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
 
-  // XCD-aware tile order: workgroup b runs on XCD b%8; give each XCD its own
-  // frame tiles and walk the node tiles fastest, so an XCD's L2 keeps its
-  // activation tiles while the (shared, L3-resident) weights stream through.
-  const int MT = p.rows_pad / G_BM, NT = p.n_pad / G_BN;
+  // Workgroup b runs on XCD b%8.  Give each XCD a contiguous band of frame tiles and
+  // walk the node tiles fastest inside it: co-resident workgroups then share the
+  // same activation rows (and all of them share the weights) in that XCD's L2.
+  const int MT = p.rows_pad / G_BM;
+  const int NT = p.n_pad / FT;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int mt = j % MT, nt = (j / MT) * 8 + xcd;
-  if (nt >= NT) return;
-  const int m0 = mt * G_BM, f0 = nt * G_BN;
+  const int per_xcd = (NT + 7) / 8;
+  const int mt = j % MT;
+  const int nt = xcd * per_xcd + j / MT;
+  if (j / MT >= per_xcd || nt >= NT) return;
+  const int m0 = mt * G_BM, f0 = nt * FT;
 
-  if (!OUTPUT)
-    for (int i = tid; i < kLutExt; i += 256) lut[i] = p.lut[i];
+  // Row strides carry a 64-byte skew on top of the power-of-two width (kRowSkew): with
+  // a 2048-byte stride every row of a tile -- and every workgroup, since they all
+  // walk k in lockstep -- would map to the same couple of L2 channels.
+  const size_t ldw = static_cast<size_t>(p.ldw), lda = static_cast<size_t>(p.lda);
+  // per-lane source offsets of the staging loads (row = slab*16 + lane/4, swizzled chunk)
+  const int srow = lane >> 2;
+  const int schunk = ((lane & 3) ^ ((srow >> 2) & 3)) << 4;
+  const int8_t *gw = p.w + static_cast<size_t>(m0 + wave * 64 + srow) * ldw + schunk;  // + slab*16 rows
+  const int8_t *ga = p.a + static_cast<size_t>(f0 + wave * 16 + srow) * lda + schunk;  // + 64 rows per extra slab
 
-  const size_t ld = static_cast<size_t>(p.K);
-  const int8_t *gw = p.w + static_cast<size_t>(m0) * ld;
-  const int8_t *ga = p.a + static_cast<size_t>(f0) * ld;
+  const int KT = p.K / G_BK;
+  auto stage = [&](int kt, int buf) {
+    char *base = smem + buf * Cfg::STAGE;
+    const int koff = kt * G_BK;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)  // weight slabs 4w .. 4w+3
+      glds16(gw + static_cast<size_t>(s * 16) * ldw + koff, base + (wave * 4 + s) * 1024);
+#pragma unroll
+    for (int s = 0; s < (Cfg::A_SLABS + 3) / 4; ++s) {  // activation slabs w, w+4, ...
+      if (s * 4 + wave < Cfg::A_SLABS)
+        glds16(ga + static_cast<size_t>(s * 64) * lda + koff, base + G_W_BYTES + (s * 4 + wave) * 1024);
+    }
+  };
 
-  v16i acc[2][2];
+  v16i acc[2][NF];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NF; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
 
-  const int KT = p.K / G_BK;
-  stage_tile(gw, ld, smem, wave, lane);
-  stage_tile(ga, ld, smem + G_TILE_BYTES, wave, lane);
-  __syncthreads();  // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < KT) stage(s, s);
 
   const int frow = lane & 31, fch = lane >> 5;
+
+  // pmaddubsw saturation (dnn.cc:337-340).  The MFMA sum is exact; the reference
+  // saturates every ADJACENT pair a[2j]*w[2j] + a[2j+1]*w[2j+1] to int16.  Only the
+  // few (node, pair) entries listed at load time can saturate at all.  Those of this
+  // wave's 64 nodes are sorted by k; when the k-step holding an entry's columns is in
+  // LDS, the pair is recomputed from the staged activation bytes and sat16(p) - p is
+  // added to the accumulator that holds (node, frame).  The entry walk and the register
+  // select are wave-uniform; a layer without risky pairs has fix_k_next = INT_MAX.
+  const FixEntry *ent = reinterpret_cast<const FixEntry *>(p.fix_ent);
+  int fix_e = 0, fix_end = 0, fix_k_next = INT_MAX;
+  if (ent) {
+    const int grp = (m0 >> 6) + wave;
+    fix_e = p.fix_grp[grp];
+    fix_end = p.fix_grp[grp + 1];
+    if (fix_e < fix_end) fix_k_next = ent[fix_e].k;
+  }
+
+  int buf = 0;
   for (int kt = 0; kt < KT; ++kt) {
-    char *cur = smem + (kt & 1) * 2 * G_TILE_BYTES;
-    if (kt + 1 < KT) {
-      char *nxt = smem + ((kt + 1) & 1) * 2 * G_TILE_BYTES;
-      stage_tile(gw + (kt + 1) * G_BK, ld, nxt, wave, lane);
-      stage_tile(ga + (kt + 1) * G_BK, ld, nxt + G_TILE_BYTES, wave, lane);
+    // stage kt has landed once at most (STAGES-2) younger stages are outstanding
+    if (STAGES > 2 && kt + STAGES - 2 < KT) {
+      if (STAGES == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::MIN_LOADS) : "memory");
+      if (STAGES == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Cfg::MIN_LOADS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    const char *wt = cur, *at = cur + G_TILE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      v4i a[2], b[2];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[mi] = read_frag(wt, 64 * wm + 32 * mi + frow, kk * 2 + fch);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) b[ni] = read_frag(at, 64 * wn + 32 * ni + frow, kk * 2 + fch);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    __builtin_amdgcn_s_barrier();  // everyone's share of stage kt landed; everyone is done reading stage kt-1
+    asm volatile("" ::: "memory");
+    if (kt + STAGES - 1 < KT) {
+      int nb = buf + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      stage(kt + STAGES - 1, nb);
     }
-    __syncthreads();
+    const char *wt = smem + buf * Cfg::STAGE;
+    const char *at = wt + G_W_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      v4i a[2], b[NF];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[mi] = read_frag(wt, 64 * wave + 32 * mi + frow, kk * 2 + fch);
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) b[ni] = read_frag(at, 32 * ni + frow, kk * 2 + fch);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    while (fix_k_next < (kt + 1) * G_BK) {  // rare: a risky pair lives in this k-step
+      const FixEntry t = ent[fix_e];
+      const int node = __builtin_amdgcn_readfirstlane(t.node) - (m0 + 64 * wave);  // 0..63
+      const int kl = __builtin_amdgcn_readfirstlane(t.k) - kt * G_BK;               // even, 0..62
+      const int w0 = __builtin_amdgcn_readfirstlane(t.w0), w1 = __builtin_amdgcn_readfirstlane(t.w1);
+      const int rr = node & 31;
+      const int idx = (node >> 5) * 16 + (rr & 3) + 4 * (rr >> 3);  // mi*16 + reg
+      const bool mine = (lane >> 5) == ((rr >> 2) & 1);
+      int c[NF];
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) {
+        const int row = 32 * ni + frow;
+        const uint32_t pair = *reinterpret_cast<const uint16_t *>(at + row * G_BK + ((((kl >> 4) ^ ((row >> 2) & 3))) << 4) + (kl & 15));
+        const int a0 = static_cast<int>((pair & 0xff) ^ 0x80), a1 = static_cast<int>((pair >> 8) ^ 0x80);  // back to u8
+        const int prod = a0 * w0 + a1 * w1;
+        c[ni] = mine ? max(-32768, min(32767, prod)) - prod : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        if (idx == i) {
+#pragma unroll
+          for (int ni = 0; ni < NF; ++ni) acc[i >> 4][ni][i & 15] += c[ni];
+        }
+      }
+      ++fix_e;
+      fix_k_next = fix_e < fix_end ? static_cast<int>(ent[fix_e].k) : INT_MAX;
+    }
+    if (++buf == STAGES) buf = 0;
   }
 
   // ------------------------------------------------------------ epilogue
+  // the ring is free now: drop the sigmoid table into LDS
+  uint8_t *lut = reinterpret_cast<uint8_t *>(smem);
+  if (!OUTPUT) {
+    __syncthreads();
+    for (int i = tid; i < kLutExt; i += 256) lut[i] = p.lut[i];
+    __syncthreads();
+  }
   // D layout (32x32): column (frame) = lane&31, row (node) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
   const int half = lane >> 5;
   const bool vec4 = (p.rows & 3) == 0;
-  float psum[2] = {0.0f, 0.0f};
+
+  float psum[NF];
+#pragma unroll
+  for (int ni = 0; ni < NF; ++ni) psum[ni] = 0.0f;
 #pragma unroll
   for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int nb = m0 + 64 * wm + 32 * mi + 8 * g + 4 * half;  // 4 consecutive nodes nb..nb+3
+      const int nb = m0 + 64 * wave + 32 * mi + 8 * g + 4 * half;  // 4 consecutive nodes nb..nb+3
       const float4 b4 = *reinterpret_cast<const float4 *>(p.bias + nb);
       const int4 ws4 = *reinterpret_cast<const int4 *>(p.wsum + nb);
-      int4 sl4 = make_int4(-1, -1, -1, -1);
-      if (p.slot) sl4 = *reinterpret_cast<const int4 *>(p.slot + nb);
       const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
       const int wj[4] = {ws4.x, ws4.y, ws4.z, ws4.w};
-      const int sj[4] = {sl4.x, sl4.y, sl4.z, sl4.w};
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        const int f = f0 + 64 * wn + 32 * ni + frow;
+      for (int ni = 0; ni < NF; ++ni) {
+        const int f = f0 + 32 * ni + frow;
         int av[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           av[q] = acc[mi][ni][g * 4 + q] + wj[q];
-          if (sj[q] >= 0) av[q] += p.corr[static_cast<size_t>(sj[q]) * p.n_pad + f];
           if (TAP && f < p.n && nb + q < p.rows) p.tap_acc[static_cast<size_t>(f) * p.rows + nb + q] = av[q];
         }
         if (!OUTPUT) {
@@ -334,44 +428,24 @@ __global__ __launch_bounds__(256, 2) void qgemm_kernel(QGemmParams p) {
   }
   if (OUTPUT) {
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
+    for (int ni = 0; ni < NF; ++ni) {
       const float tot = psum[ni] + __shfl_xor(psum[ni], 32);
-      const int f = f0 + 64 * wn + 32 * ni + frow;
-      if (half == 0) p.partial[static_cast<size_t>(mt * 2 + wm) * p.n_pad + f] = tot;
+      const int f = f0 + 32 * ni + frow;
+      if (half == 0) p.partial[static_cast<size_t>(mt * 4 + wave) * p.partial_ld + f] = tot;
     }
   }
-}
-
-// ---------------------------------------------------------------- saturation corrections
-__global__ __launch_bounds__(256) void fix_kernel(FixParams p) {
-  const int s = blockIdx.x;
-  const int f = blockIdx.y * 256 + threadIdx.x;
-  if (f >= p.n_pad) return;
-  int c = 0;
-  if (f < p.n) {
-    const FixEntry *ent = reinterpret_cast<const FixEntry *>(p.fix_ent);
-    const uint8_t *row = reinterpret_cast<const uint8_t *>(p.a) + static_cast<size_t>(f) * p.K;
-    for (int e = p.fix_ptr[s]; e < p.fix_ptr[s + 1]; ++e) {
-      const FixEntry t = ent[e];
-      const uint16_t pair = *reinterpret_cast<const uint16_t *>(row + t.k);  // k is even
-      const int a0 = (pair & 0xff) ^ 0x80, a1 = (pair >> 8) ^ 0x80;         // back to u8
-      const int prod = a0 * t.w0 + a1 * t.w1;
-      c += max(-32768, min(32767, prod)) - prod;                             // pmaddubsw, dnn.cc:337-340
-    }
-  }
-  p.corr[static_cast<size_t>(s) * p.n_pad + f] = c;
 }
 
 // ---------------------------------------------------------------- soft-max normalisation
 // SoftMax::apply second loop (dnn.cc:541-543): p_i = e_i / total.  total is the
 // sum of the output kernel's per-64-node partials in a fixed order.
-__global__ __launch_bounds__(256) void normalize_kernel(float *out, const float *partial, int n, int n_pad, int rows,
+__global__ __launch_bounds__(256) void normalize_kernel(float *out, const float *partial, int n, int partial_ld, int rows,
                                                         int n_partial) {
   __shared__ float red[4];
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
   float s = 0.0f;
-  for (int t = tid; t < n_partial; t += 256) s += partial[static_cast<size_t>(t) * n_pad + f];
+  for (int t = tid; t < n_partial; t += 256) s += partial[static_cast<size_t>(t) * partial_ld + f];
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
   if ((tid & 63) == 0) red[tid >> 6] = s;
@@ -414,8 +488,7 @@ __global__ __launch_bounds__(256) void xor80_kernel(const int8_t *in, uint8_t *o
 
 // ---------------------------------------------------------------- launchers
 void launch_l0(const L0Params &p, hipStream_t s) {
-  const int n_pad = (p.n + kFrameTile - 1) / kFrameTile * kFrameTile;
-  dim3 grid((p.H + L0_TN - 1) / L0_TN, n_pad / L0_TF);
+  dim3 grid((p.H + L0_TN - 1) / L0_TN, (p.n_rows + L0_TF - 1) / L0_TF);
   if (p.tap_lin) {
     if (p.fma)
       hipLaunchKernelGGL((l0_kernel<true, true>), grid, dim3(256), 0, s, p);
@@ -429,40 +502,64 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   }
 }
 
-template <bool OUTPUT>
-static void launch_qgemm(const QGemmParams &p, hipStream_t s) {
-  const int MT = p.rows_pad / G_BM, NT = p.n_pad / G_BN;
+int qgemm_frame_tile(int rows_pad, int n) {
+  // Pick the frame tile (128 / 160 / 192) that minimises rounds x tile cost, where a
+  // round is 2 workgroups on each of the 256 CUs; ties go to the larger tile (more
+  // reuse per byte staged).
+  const int mt = rows_pad / G_BM;
+  int best = 128;
+  long best_cost = -1;
+  for (int ft : {128, 160, 192}) {
+    const long blocks = static_cast<long>(mt) * ((n + ft - 1) / ft);
+    const long rounds = (blocks + 511) / 512;
+    const long cost = rounds * ft;
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && ft > best)) {
+      best_cost = cost;
+      best = ft;
+    }
+  }
+  return best;
+}
+
+namespace {
+
+template <int NF, bool OUTPUT>
+void launch_qgemm_nf(const QGemmParams &p, hipStream_t s) {
+  constexpr int STAGES = 3;
+  constexpr int lds = gemm_lds_bytes<NF, STAGES>();
+  const int MT = p.rows_pad / G_BM, NT = p.n_pad / (32 * NF);
   const int blocks = 8 * MT * ((NT + 7) / 8);
-  const bool tap = p.tap_acc != nullptr;
+  auto k_prod = qgemm_kernel<NF, STAGES, OUTPUT, false>;
+  auto k_tap = qgemm_kernel<NF, STAGES, OUTPUT, true>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&qgemm_kernel<false, false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&qgemm_kernel<false, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&qgemm_kernel<true, false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&qgemm_kernel<true, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_prod), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_tap), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  if (tap)
-    hipLaunchKernelGGL((qgemm_kernel<OUTPUT, true>), dim3(blocks), dim3(256), G_LDS_BYTES, s, p);
+  if (p.tap_acc)
+    hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(256), lds, s, p);
   else
-    hipLaunchKernelGGL((qgemm_kernel<OUTPUT, false>), dim3(blocks), dim3(256), G_LDS_BYTES, s, p);
+    hipLaunchKernelGGL(k_prod, dim3(blocks), dim3(256), lds, s, p);
 }
+
+template <bool OUTPUT>
+void launch_qgemm(const QGemmParams &p, hipStream_t s) {
+  switch (p.frame_tile) {
+    case 128: launch_qgemm_nf<4, OUTPUT>(p, s); break;
+    case 160: launch_qgemm_nf<5, OUTPUT>(p, s); break;
+    default: launch_qgemm_nf<6, OUTPUT>(p, s); break;
+  }
+}
+
+}  // namespace
 
 void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s) { launch_qgemm<false>(p, s); }
 void launch_qgemm_output(const QGemmParams &p, hipStream_t s) { launch_qgemm<true>(p, s); }
 
-void launch_fix(const FixParams &p, hipStream_t s) {
-  if (p.n_slots <= 0) return;
-  hipLaunchKernelGGL(fix_kernel, dim3(p.n_slots, (p.n_pad + 255) / 256), dim3(256), 0, s, p);
-}
-
-void launch_normalize(float *out, const float *partial, int n, int n_pad, int rows, int n_partial, hipStream_t s) {
+void launch_normalize(float *out, const float *partial, int n, int partial_ld, int rows, int n_partial, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(normalize_kernel, dim3(n), dim3(256), 0, s, out, partial, n, n_pad, rows, n_partial);
+  hipLaunchKernelGGL(normalize_kernel, dim3(n), dim3(256), 0, s, out, partial, n, partial_ld, rows, n_partial);
 }
 
 void launch_fastdiv_check(float coef, float rcp, unsigned long long *d_mismatch, hipStream_t s) {

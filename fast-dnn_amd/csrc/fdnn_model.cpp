@@ -1,6 +1,7 @@
 // fdnn_model.cpp -- .bin loader, quantizer and weight-blob packer (host only).
 #include "fdnn_model.hpp"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -136,7 +137,7 @@ int pack(const std::vector<RawLayer> &layers, const std::vector<float> &shift, c
   // quantize first: section sizes depend on the fix-up lists
   struct QTmp {
     std::vector<int8_t> wq;
-    std::vector<int32_t> wsum, slot, fix_ptr;
+    std::vector<int32_t> wsum, fix_grp;
     std::vector<FixEntry> ent;
     float mult = 0;
     int cols_pad = 0;
@@ -147,7 +148,9 @@ int pack(const std::vector<RawLayer> &layers, const std::vector<float> &shift, c
     QTmp &t = qt[size_t(qi)];
     const int rows = L.out_dim, cols = L.in_pad;
     const int rows_pad = int(align_up(size_t(rows), kRowPad));
-    const int cols_pad = int(align_up(size_t(cols), kColPad));
+    // row stride: k extent padded to the GEMM k-step, plus the skew that keeps the rows
+    // of a tile off the same L2 channels (see qgemm_kernel)
+    const int cols_pad = int(align_up(size_t(cols), kColPad)) + kRowSkew;
     t.cols_pad = cols_pad;
     t.wq.assign(size_t(rows_pad) * cols_pad, 0);
     {
@@ -156,28 +159,36 @@ int pack(const std::vector<RawLayer> &layers, const std::vector<float> &shift, c
       for (int r = 0; r < rows; ++r) std::memcpy(&t.wq[size_t(r) * cols_pad], &dense[size_t(r) * cols], size_t(cols));
     }
     t.wsum.assign(size_t(rows_pad), 0);
-    t.slot.assign(size_t(rows_pad), -1);
-    t.fix_ptr.push_back(0);
+    t.fix_grp.assign(size_t(rows_pad) / 64 + 1, 0);
     for (int r = 0; r < rows; ++r) {
       const int8_t *wr = &t.wq[size_t(r) * cols_pad];
       int32_t s = 0;
-      bool any = false;
+      const size_t first = t.ent.size();
       for (int k = 0; k < cols; k += 2) {
         const int w0 = wr[k], w1 = wr[k + 1];
         s += w0 + w1;
+        // the pair sum a0*w0 + a1*w1 (a in 0..255) can leave int16 for SOME activation
+        // iff 255*(w0^+ + w1^+) > 32767 or 255*(w0^- + w1^-) < -32768
         const int pos = (w0 > 0 ? w0 : 0) + (w1 > 0 ? w1 : 0);
         const int neg = (w0 < 0 ? w0 : 0) + (w1 < 0 ? w1 : 0);
-        if (255 * pos > 32767 || 255 * neg < -32768) {
-          t.ent.push_back(FixEntry{uint16_t(k), int8_t(w0), int8_t(w1)});
-          any = true;
-        }
+        if (255 * pos > 32767 || 255 * neg < -32768) t.ent.push_back(FixEntry{uint16_t(k), int8_t(w0), int8_t(w1), r});
       }
       t.wsum[size_t(r)] = 128 * s;
-      if (any) {
-        t.slot[size_t(r)] = int32_t(t.fix_ptr.size()) - 1;
-        t.fix_ptr.push_back(int32_t(t.ent.size()));
+      (void)first;
+      if (t.ent.size() > size_t(kMaxFixPerLayer)) {
+        *msg = "layer " + std::to_string(qi + 1) + ": more than " + std::to_string(kMaxFixPerLayer) +
+               " weight pairs whose pmaddubsw sum can saturate; the sparse correction path is not sized for that";
+        return FDNN_E_FORMAT;
       }
+      if ((r & 63) == 63) t.fix_grp[size_t(r) / 64 + 1] = int32_t(t.ent.size());
     }
+    // close the ranges of a partial last group and of the padding groups
+    for (size_t gi = size_t(rows + 63) / 64; gi < t.fix_grp.size(); ++gi) t.fix_grp[gi] = int32_t(t.ent.size());
+    // inside a 64-node group the GEMM consumes the entries in k order (as its k-loop
+    // brings the columns through LDS)
+    for (size_t gi = 0; gi + 1 < t.fix_grp.size(); ++gi)
+      std::stable_sort(t.ent.begin() + t.fix_grp[gi], t.ent.begin() + t.fix_grp[gi + 1],
+                       [](const FixEntry &a, const FixEntry &b) { return a.k < b.k; });
   }
 
   size_t off = align_up(sizeof(BlobHeader), 256);
@@ -199,7 +210,6 @@ int pack(const std::vector<RawLayer> &layers, const std::vector<float> &shift, c
     d.cols = L.in_pad;
     d.cols_pad = t.cols_pad;
     d.rows_pad = int32_t(t.wsum.size());
-    d.n_slots = int32_t(t.fix_ptr.size()) - 1;
     d.n_fix = int32_t(t.ent.size());
     d.mult = t.mult;
     d.coef = t.mult * 255.0f;
@@ -208,8 +218,7 @@ int pack(const std::vector<RawLayer> &layers, const std::vector<float> &shift, c
     d.off_w = place(t.wq.size());
     d.off_bias = place(sizeof(float) * size_t(d.rows_pad));
     d.off_wsum = place(sizeof(int32_t) * size_t(d.rows_pad));
-    d.off_slot = place(sizeof(int32_t) * size_t(d.rows_pad));
-    d.off_fix_ptr = place(sizeof(int32_t) * t.fix_ptr.size());
+    d.off_fix_grp = place(sizeof(int32_t) * t.fix_grp.size());
     d.off_fix_ent = place(sizeof(FixEntry) * (t.ent.size() + 1));
   }
   h.total_bytes = off;
@@ -237,8 +246,7 @@ int pack(const std::vector<RawLayer> &layers, const std::vector<float> &shift, c
     std::memcpy(b + d.off_w, t.wq.data(), t.wq.size());
     std::memcpy(b + d.off_bias, L.bias.data(), sizeof(float) * size_t(d.rows));
     std::memcpy(b + d.off_wsum, t.wsum.data(), sizeof(int32_t) * t.wsum.size());
-    std::memcpy(b + d.off_slot, t.slot.data(), sizeof(int32_t) * t.slot.size());
-    std::memcpy(b + d.off_fix_ptr, t.fix_ptr.data(), sizeof(int32_t) * t.fix_ptr.size());
+    std::memcpy(b + d.off_fix_grp, t.fix_grp.data(), sizeof(int32_t) * t.fix_grp.size());
     if (!t.ent.empty()) std::memcpy(b + d.off_fix_ent, t.ent.data(), sizeof(FixEntry) * t.ent.size());
   }
   std::memcpy(b, &h, sizeof(h));

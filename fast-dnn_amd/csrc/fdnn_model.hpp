@@ -20,9 +20,11 @@ constexpr int kLutHalf = 640;       // dnn.h:27
 constexpr int kLutExt = 1281;       // device table: index clamp(k,-640,640)+640
 constexpr int kMaxQLayers = 30;
 constexpr uint32_t kBlobMagic = 0x4e4e4446u;  // "FDNN"
-constexpr uint32_t kBlobVersion = 3;
+constexpr uint32_t kBlobVersion = 5;
 constexpr int kRowPad = 256;        // int8 weight rows padded to the GEMM node tile
 constexpr int kColPad = 128;        // int8 weight columns (and activation rows) padded to the GEMM k-step
+constexpr int kRowSkew = 0;         // extra bytes on int8 row strides (0: measured slower with a 64-byte skew)
+constexpr int kMaxFixPerLayer = 1 << 20;  // saturating pairs one layer may carry (each costs a gather per frame tile)
 
 // One (node, adjacent weight pair) entry whose pmaddubsw pair sum can leave
 // int16 for some activation (dnn.cc:337-340): k is the even column.
@@ -30,22 +32,23 @@ struct FixEntry {
   uint16_t k;
   int8_t w0;
   int8_t w1;
+  int32_t node;
 };
 
 struct QLayerDesc {       // lives in the blob header, read by host and device
   uint64_t off_w;         // int8 [rows_pad][cols_pad], pad rows / pad columns are zero
   uint64_t off_bias;      // f32 [rows_pad]
   uint64_t off_wsum;      // i32 [rows_pad]  128 * sum_k w[row][k]
-  uint64_t off_slot;      // i32 [rows_pad]  -1, or row of the correction matrix
-  uint64_t off_fix_ptr;   // i32 [n_slots+1]
-  uint64_t off_fix_ent;   // FixEntry [n_fix]
+  uint64_t off_fix_grp;   // i32 [rows_pad/64 + 1]  entry range of each 64-node group
+  uint64_t off_fix_ent;   // FixEntry [n_fix], sorted by node
   int32_t rows, rows_pad, cols;
-  int32_t n_slots, n_fix;
+  int32_t n_fix;          // risky (node, pair) entries in this layer
+  int32_t pad0_;
   float mult;             // QuantizedSimdLayer::multiplier_
   float coef;             // mult * 255.0f  (dnn.cc:298-299)
   float rcp_coef;         // RN(1/coef) for the 3-op exact division
   int32_t fastdiv_ok;     // set after the exhaustive device check at load
-  int32_t cols_pad;       // cols padded to the GEMM k-step (kColPad)
+  int32_t cols_pad;       // row stride of w: cols padded to the GEMM k-step (kColPad) + kRowSkew
 };
 
 struct BlobHeader {

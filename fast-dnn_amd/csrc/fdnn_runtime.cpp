@@ -60,7 +60,7 @@ struct fdnn_model {
 
 struct fdnn_ctx {
   fdnn_model *m = nullptr;
-  int n = 0, n_pad = 0;  // frames in use, padded to the GEMM frame tile
+  int n = 0;              // frames in use
   int cap = 0;            // frames the scratch was allocated for (padded)
   int act_ld = 0;
   hipStream_t stream = nullptr;   // own stream for the host-pointer entry points
@@ -70,7 +70,6 @@ struct fdnn_ctx {
   float *d_out = nullptr;         // [n][O]
   float *d_partial = nullptr;     // [rows_pad/64][n_pad]
   int8_t *d_mask = nullptr;       // [n][O]
-  int32_t *d_corr = nullptr;      // [max n_slots][n_pad]
   int last = -1;                  // d_act index holding the last hidden layer, -1 = not computed
   bool pooled = false;
 };
@@ -139,7 +138,6 @@ void destroy_ctx(fdnn_ctx *c) {
   hipFree(c->d_out);
   hipFree(c->d_partial);
   hipFree(c->d_mask);
-  hipFree(c->d_corr);
   if (c->done) hipEventDestroy(c->done);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -152,28 +150,26 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
   fdnn_ctx *c = new fdnn_ctx();
   c->m = m;
   c->n = n;
-  c->n_pad = round_up(std::max(n, 1), fdnn::kFrameTile);
-  c->cap = c->n_pad;
-  c->act_ld = round_up(h.hidden, fdnn::kColPad);
-  int max_slots = 0, max_rows_pad = 0;
+  c->cap = round_up(std::max(n, 1), 64);
+  c->act_ld = round_up(h.hidden, fdnn::kColPad) + fdnn::kRowSkew;
+  int max_rows_pad = 0;
   for (int qi = 0; qi < h.n_q; ++qi) {
-    max_slots = std::max(max_slots, h.q[qi].n_slots);
     max_rows_pad = std::max(max_rows_pad, h.q[qi].rows_pad);
   }
-  const size_t np = size_t(c->n_pad);
+  const size_t np = size_t(c->cap);
+  // the GEMMs work on whole frame tiles: every frame-indexed scratch carries one
+  // tile of slack rows (a launch covers [first, first + round_up(count, tile)))
+  const size_t npt = np + fdnn::kMaxFrameTile;
   hipError_t e = hipSuccess;
   auto alloc = [&](void **p, size_t bytes) {
     if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16);
   };
   alloc(reinterpret_cast<void **>(&c->d_x), sizeof(float) * np * h.in_dim);
-  // one extra frame tile of slack: an output sub-range may start at any frame and
-  // the GEMM always reads whole 128-frame tiles of activation rows
-  alloc(reinterpret_cast<void **>(&c->d_act[0]), (np + fdnn::kFrameTile) * c->act_ld);
-  alloc(reinterpret_cast<void **>(&c->d_act[1]), (np + fdnn::kFrameTile) * c->act_ld);
+  alloc(reinterpret_cast<void **>(&c->d_act[0]), npt * c->act_ld);
+  alloc(reinterpret_cast<void **>(&c->d_act[1]), npt * c->act_ld);
   alloc(reinterpret_cast<void **>(&c->d_out), sizeof(float) * np * h.out_dim);
-  alloc(reinterpret_cast<void **>(&c->d_partial), sizeof(float) * np * (max_rows_pad / fdnn::kPartialNodes));
+  alloc(reinterpret_cast<void **>(&c->d_partial), sizeof(float) * npt * (max_rows_pad / fdnn::kPartialNodes));
   alloc(reinterpret_cast<void **>(&c->d_mask), np * h.out_dim);
-  alloc(reinterpret_cast<void **>(&c->d_corr), sizeof(int32_t) * np * std::max(max_slots, 1));
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -228,6 +224,36 @@ int snapshot_acts(const fdnn_ctx *c, int buf, uint8_t *d_dst, hipStream_t s) {
   return FDNN_OK;
 }
 
+// GEMM descriptor of one int8 layer over `n` frames starting at activation row
+// `act` (frame tile chosen for this n).
+fdnn::QGemmParams prepare_qlayer(fdnn_ctx *c, const QLayerDesc &d, const int8_t *act, int n, hipStream_t s) {
+  fdnn_model *m = c->m;
+  const BlobHeader &h = m->hm.hdr;
+  const uint8_t *B = m->d_blob;
+  fdnn::QGemmParams g{};
+  g.frame_tile = fdnn::qgemm_frame_tile(d.rows_pad, n);
+  g.n = n;
+  g.n_pad = round_up(n, g.frame_tile);
+  if (d.n_fix > 0) {
+    g.fix_grp = reinterpret_cast<const int32_t *>(B + d.off_fix_grp);
+    g.fix_ent = B + d.off_fix_ent;
+  }
+  g.w = reinterpret_cast<const int8_t *>(B + d.off_w);
+  g.a = act;
+  g.bias = reinterpret_cast<const float *>(B + d.off_bias);
+  g.wsum = reinterpret_cast<const int32_t *>(B + d.off_wsum);
+  g.lut = B + h.off_lut;
+  g.rows = d.rows;
+  g.rows_pad = d.rows_pad;
+  g.K = d.cols_pad - fdnn::kRowSkew;
+  g.ldw = d.cols_pad;
+  g.lda = c->act_ld;
+  g.coef = d.coef;
+  g.rcp_coef = d.rcp_coef;
+  g.fastdiv = d.fastdiv_ok;
+  return g;
+}
+
 // CalculateUntilLastHiddenLayer (dnn.cc:402-424): layer 0, then every int8
 // hidden layer, layer-major over the whole frame batch.
 int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
@@ -245,6 +271,7 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
   l0.act_ld = c->act_ld;
   l0.tap_lin = taps ? taps->l0_lin : nullptr;
   l0.n = c->n;
+  l0.n_rows = c->n;
   l0.D = h.in_dim;
   l0.H = h.hidden;
   l0.fma = m->l0_fma;
@@ -255,36 +282,7 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
   int cur = 0;
   if (taps && taps->u8_acts) snapshot_acts(c, cur, taps->u8_acts, s);
   for (int qi = 0; qi < h.n_q - 1; ++qi) {
-    const QLayerDesc &d = h.q[qi];
-    if (d.n_slots > 0) {
-      fdnn::FixParams fp{};
-      fp.a = c->d_act[cur];
-      fp.fix_ptr = reinterpret_cast<const int32_t *>(B + d.off_fix_ptr);
-      fp.fix_ent = B + d.off_fix_ent;
-      fp.corr = c->d_corr;
-      fp.n_slots = d.n_slots;
-      fp.n = c->n;
-      fp.n_pad = c->n_pad;
-      fp.K = c->act_ld;
-      ProfScope ps(m, s, FDNN_PROF_FIX);
-      fdnn::launch_fix(fp, s);
-    }
-    fdnn::QGemmParams g{};
-    g.w = reinterpret_cast<const int8_t *>(B + d.off_w);
-    g.a = c->d_act[cur];
-    g.bias = reinterpret_cast<const float *>(B + d.off_bias);
-    g.wsum = reinterpret_cast<const int32_t *>(B + d.off_wsum);
-    g.slot = d.n_slots > 0 ? reinterpret_cast<const int32_t *>(B + d.off_slot) : nullptr;
-    g.corr = d.n_slots > 0 ? c->d_corr : nullptr;
-    g.lut = B + h.off_lut;
-    g.rows = d.rows;
-    g.rows_pad = d.rows_pad;
-    g.K = d.cols_pad;
-    g.n = c->n;
-    g.n_pad = c->n_pad;
-    g.coef = d.coef;
-    g.rcp_coef = d.rcp_coef;
-    g.fastdiv = d.fastdiv_ok;
+    fdnn::QGemmParams g = prepare_qlayer(c, h.q[qi], c->d_act[cur], c->n, s);
     g.act_out = c->d_act[cur ^ 1];
     g.act_ld = c->act_ld;
     g.tap_acc = (taps && taps->acc_hid) ? taps->acc_hid + size_t(qi) * c->n * h.hidden : nullptr;
@@ -302,49 +300,19 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
 
 // CalculateOutput (dnn.cc:428-454) / LazyOutputActivations (dnn.cc:355-392)
 // over frames [first, first+count) of the context's last hidden activations.
+// Rows [first+count, first+n_pad) are read by the GEMM as padding frames; the
+// activation buffers carry one tile of slack rows for that.
 int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out, hipStream_t s, const Taps *taps) {
   fdnn_model *m = c->m;
   const BlobHeader &h = m->hm.hdr;
-  const uint8_t *B = m->d_blob;
   const QLayerDesc &d = h.q[h.n_q - 1];
   if (c->last < 0) return fail(FDNN_E_STATE, "output requested before the hidden layers were computed");
   if (first < 0 || count < 0 || first + count > c->n) return fail(FDNN_E_ARG, "frame range outside the context");
   if (count == 0) return FDNN_OK;
-  const int8_t *act = c->d_act[c->last] + size_t(first) * c->act_ld;
-  // rows [first+count, first+n_pad) are read by the GEMM as padding frames; the
-  // activation buffers carry one tile of slack rows for that.
-  const int n_pad = round_up(count, fdnn::kFrameTile);
-  if (d.n_slots > 0) {
-    fdnn::FixParams fp{};
-    fp.a = act;
-    fp.fix_ptr = reinterpret_cast<const int32_t *>(B + d.off_fix_ptr);
-    fp.fix_ent = B + d.off_fix_ent;
-    fp.corr = c->d_corr;
-    fp.n_slots = d.n_slots;
-    fp.n = count;
-    fp.n_pad = n_pad;
-    fp.K = c->act_ld;
-    ProfScope ps(m, s, FDNN_PROF_FIX);
-    fdnn::launch_fix(fp, s);
-  }
-  fdnn::QGemmParams g{};
-  g.w = reinterpret_cast<const int8_t *>(B + d.off_w);
-  g.a = act;
-  g.bias = reinterpret_cast<const float *>(B + d.off_bias);
-  g.wsum = reinterpret_cast<const int32_t *>(B + d.off_wsum);
-  g.slot = d.n_slots > 0 ? reinterpret_cast<const int32_t *>(B + d.off_slot) : nullptr;
-  g.corr = d.n_slots > 0 ? c->d_corr : nullptr;
-  g.lut = B + h.off_lut;
-  g.rows = d.rows;
-  g.rows_pad = d.rows_pad;
-  g.K = d.cols_pad;
-  g.n = count;
-  g.n_pad = n_pad;
-  g.coef = d.coef;
-  g.rcp_coef = d.rcp_coef;
-  g.fastdiv = d.fastdiv_ok;
+  fdnn::QGemmParams g = prepare_qlayer(c, d, c->d_act[c->last] + size_t(first) * c->act_ld, count, s);
   g.out = d_out;
   g.partial = c->d_partial;
+  g.partial_ld = g.n_pad;
   g.mask = d_masks;
   g.tap_acc = taps ? taps->acc_out : nullptr;
   g.tap_logit = taps ? taps->logits : nullptr;
@@ -354,7 +322,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   }
   {
     ProfScope ps(m, s, FDNN_PROF_NORMALIZE);
-    fdnn::launch_normalize(d_out, c->d_partial, count, n_pad, d.rows, d.rows_pad / fdnn::kPartialNodes, s);
+    fdnn::launch_normalize(d_out, c->d_partial, count, g.partial_ld, d.rows, d.rows_pad / fdnn::kPartialNodes, s);
   }
   HIP_TRY(hipGetLastError());
   return FDNN_OK;
@@ -380,7 +348,6 @@ int acquire_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
     c->pooled = true;
   }
   c->n = n;
-  c->n_pad = round_up(std::max(n, 1), fdnn::kFrameTile);
   c->last = -1;
   *out = c;
   return FDNN_OK;

@@ -206,6 +206,7 @@ def synth_net(
             lim = np.float32(3.2 * std)
             np.clip(w, -lim, lim, out=w)
             w[n_out // 2, n_in // 2] = np.float32(2.0) * lim
+            w[n_out // 2, (n_in // 2) ^ 1] = 0.0  # its pmaddubsw pair partner: keeps the pair below the int16 limit
         layers.append(FloatLayerSpec(w, b))
     n_in0 = int(topology[0])
     shift = rng.standard_normal(n_in0, dtype=np.float32) * np.float32(0.1)
