@@ -134,7 +134,8 @@ def main() -> None:
 
     # sanity on the last output: soft-max rows sum to one
     row_sum = float(out[:64].sum(1).mean().item())
-    assert abs(row_sum - 1.0) < 1e-3, row_sum
+    if not os.environ.get("FDNN_BENCH_NOCHECK"):  # (set only for kernel-ablation timing builds)
+        assert abs(row_sum - 1.0) < 1e-3, row_sum
 
     # second pass over the same K steps with per-kernel HIP events (rank 0 reports)
     dnn.profileBegin()

@@ -16,7 +16,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfast-dnn.so")
+LIB_PATH = os.environ.get("FDNN_LIB") or os.path.join(_HERE, "lib", "libfast-dnn.so")  # FDNN_LIB: experiment builds
 CSRC = os.path.join(_HERE, "csrc")
 
 FDNN_OK, FDNN_E_ARG, FDNN_E_IO, FDNN_E_FORMAT, FDNN_E_DEVICE, FDNN_E_NOMEM, FDNN_E_STATE = 0, -1, -2, -3, -4, -5, -6

@@ -1,0 +1,54 @@
+// fdnn_device.hpp -- device helpers shared by the gfx950 kernels.  Everything here
+// is compiled with -ffp-contract=off: each float operation rounds exactly where
+// the reference's scalar/SSE code rounds; fused multiply-adds appear only where
+// written as fmaf().
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "fdnn_model.hpp"
+
+namespace fdnn {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+#define FDNN_LDS_PTR(p) ((__attribute__((address_space(3))) void *)(p))
+#define FDNN_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void *)(p))
+
+// 16 bytes per lane straight from global memory into LDS at
+// wave-uniform base + lane*16 (global_load_lds_dwordx4).
+__device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(FDNN_GLOBAL_PTR(g), FDNN_LDS_PTR(lds_wave_base), 16, 0, 0);
+}
+
+// float(sum) / (multiplier * 255)   -- dnn.cc:298-299, :311.  The fast form is
+// the Markstein sequence q = x*y, r = fma(-q, c, x), q' = fma(r, y, q) with
+// y = RN(1/c); it is enabled per layer only after launch_fastdiv_check has
+// compared it with IEEE division for every possible accumulator.
+template <bool FAST>
+__device__ __forceinline__ float dequant(int acc, float coef, float rcp) {
+  const float x = static_cast<float>(acc);  // v_cvt_f32_i32, RNE like cvtsi2ss
+  if (FAST) {
+    const float q = x * rcp;
+    const float r = fmaf(-q, coef, x);
+    return fmaf(r, rcp, q);
+  }
+  return x / coef;
+}
+
+// QuantizedSigmoid::get -- dnn.h:36-43: k = (int)round(x*100), table index
+// clamp(k,-640,640)+640 into the extended table.  round() is half away from
+// zero; the x86 build turns NaN / |t| >= 2^31 into INT_MIN (-> entry 0).
+__device__ __forceinline__ int lut_index(float lin) {
+  const float t = lin * 100.0f;
+  const float r0 = truncf(t);
+  // t - r0 is exact; select, do not branch (the epilogue runs this 32*NF times per lane)
+  const float r = r0 + ((fabsf(t - r0) >= 0.5f) ? copysignf(1.0f, t) : 0.0f);
+  int k = (fabsf(t) < 2147483648.0f) ? static_cast<int>(r) : INT_MIN;
+  k = max(-kLutHalf, min(kLutHalf, k));
+  return k + kLutHalf;
+}
+
+}  // namespace fdnn

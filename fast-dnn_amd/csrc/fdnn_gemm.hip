@@ -1,0 +1,547 @@
+// fdnn_gemm.hip -- the int8 layer kernel (MFMA 32x32x32 i8) for gfx950.
+//
+//   QuantizedLayerActivations/quantizedNodeSum + AddBias + QuantizedSigmoid
+//     (dnn.cc:289-349, :250-286)                      -> qgemm_kernel<.., OUTPUT=false>
+//   CalculateOutput / LazyOutputActivations + SoftMax first loop
+//     (dnn.cc:428-454, :355-392, :534-540)            -> qgemm_kernel<.., OUTPUT=true>
+//   pmaddubsw int16 pair saturation (dnn.cc:337-340)  -> sparse exact correction inside the k-loop
+//
+// u8 x s8 on signed MFMA: activations travel as s8 = u8 - 128 (bit 7 flipped),
+// so sum_k u8*w = sum_k s8*w + 128*sum_k w; the second term is a per-node int32
+// precomputed at load.  Exact: |sum| <= 2^15 * 255 * 128 < 2^31.
+//
+// C[node][frame] = sum_k W[node][k] * A[frame][k].  Both operands are K-contiguous
+// byte rows, so both MFMA fragments are plain 16-byte row slices.
+//
+// Workgroup tile: 256 nodes x FT = 32*NF*WN frames, 4*WN waves.  Wave (wm, wn) owns
+// nodes [64wm, 64wm+64) x frames [32*NF*wn, +32*NF) = 2 x NF MFMA 32x32 tiles
+// (32*NF accumulator registers).
+//
+// L2 -> LDS: global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave instruction) into a
+// ring of STAGES buffers, one raw barrier per k-step, loads kept in flight across
+// it with a counted s_waitcnt vmcnt.  The k-step is BK bytes of every row; with
+// BK = 128 each row segment is one whole 128-byte cache line, which the vector
+// L1 serves at twice the rate of 64-byte segments (tools/ubench_glds.hip:
+// 29 vs 17 TB/s chip-wide from L2).
+//
+// LDS image: rows of BK bytes; 16-byte chunk c of row r is stored at chunk
+// c ^ swz(r) with swz(r) = (r>>2)&3 for 64-byte rows (4 rows per 256-B bank row)
+// and (r>>1)&7 for 128-byte rows (2 rows per bank row).  The XOR is applied to the
+// per-lane GLOBAL address while the LDS destination stays lane-linear, and again
+// on the ds_read_b128 fragment reads, so every 16-lane read group hits 16
+// distinct 16-byte slots (conflict free; SQ_LDS_BANK_CONFLICT ~ 0).
+#include "fdnn_device.hpp"
+#include "fdnn_kernels.hpp"
+
+#include <cstdlib>
+
+// Timing experiments only (never set in the shipped build): bit 0 = no staging
+// loads after the prologue, bit 1 = no MFMA, bit 2 = no LDS fragment reads.
+#ifndef FDNN_GEMM_DEBUG
+#define FDNN_GEMM_DEBUG 0
+#endif
+
+namespace fdnn {
+namespace {
+
+constexpr int G_BM = 256;
+constexpr int kFixCap = 64;  // saturation-fix entries per 64-node group kept in LDS (the rest: global, slow)
+
+template <int NF, int WN, int BK, int STAGES>
+struct GemmCfg {
+  static constexpr int NW = 4 * WN;                  // waves
+  static constexpr int THREADS = 64 * NW;
+  static constexpr int FT = 32 * NF * WN;            // frames per workgroup tile
+  static constexpr int RPI = 1024 / BK;              // rows per 1-KiB wave instruction
+  static constexpr int LPR = BK / 16;                // lanes per row
+  static constexpr int W_BYTES = G_BM * BK;
+  static constexpr int A_BYTES = FT * BK;
+  static constexpr int STAGE = W_BYTES + A_BYTES;
+  static constexpr int W_SLABS = G_BM / RPI;
+  static constexpr int A_SLABS = FT / RPI;
+  static constexpr int MIN_LOADS = W_SLABS / NW + A_SLABS / NW;  // fewest loads any wave issues per stage
+  // after the k-loop the ring is reused for the sigmoid table (3 KiB) + biases + offsets (2 KiB)
+  // and, for hidden layers, the s8 output tile FT x (256+16) bytes.  Behind the ring:
+  // 4 node groups x kFixCap saturation-fix entries.
+  static constexpr int EPI = 8192 + FT * (G_BM + 16);
+  static constexpr int RING = STAGE * STAGES + 4 * kFixCap * 8;
+  static constexpr int LDS = RING > EPI ? RING : EPI;
+  static_assert(W_SLABS % NW == 0, "weight slabs must split evenly over the waves");
+  static_assert(LDS <= 160 * 1024, "LDS ring exceeds the CU");
+};
+
+template <int BK>
+__device__ __forceinline__ int swz(int row) {
+  return BK == 64 ? ((row >> 2) & 3) : ((row >> 1) & 7);
+}
+
+template <int BK>
+__device__ __forceinline__ v4i read_frag(const char *tile, int row, int chunk) {
+  return *reinterpret_cast<const v4i *>(tile + row * BK + ((chunk ^ swz<BK>(row)) << 4));
+}
+
+// FAST: the layer's 3-op division was validated against IEEE division at load
+// (every layer of a sane net); !FAST keeps the true divide for the rest.
+template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool TAP, bool FAST>
+__global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (buffer-resource builtins are device-only)
+  using Cfg = GemmCfg<NF, WN, BK, STAGES>;
+  constexpr int FT = Cfg::FT, NW = Cfg::NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#if FDNN_GEMM_DEBUG & 64
+  long long ts[6];
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+  ts[0] = __builtin_readcyclecounter();
+#define FDNN_TS(i) ts[i] = __builtin_readcyclecounter()
+#else
+#define FDNN_TS(i)
+#endif
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+
+  // Workgroup b runs on XCD b%8.  Give each XCD a contiguous band of frame tiles and
+  // walk the node tiles fastest inside it: co-resident workgroups then share the
+  // same activation rows (and all of them share the weights) in that XCD's L2.
+  const int MT = p.rows_pad / G_BM;
+  const int NT = p.n_pad / FT;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int per_xcd = (NT + 7) / 8;
+  const int mt = j % MT;
+  const int nt = xcd * per_xcd + j / MT;
+  if (j / MT >= per_xcd || nt >= NT) return;
+  const int m0 = mt * G_BM, f0 = nt * FT;
+
+  const size_t ldw = static_cast<size_t>(p.ldw), lda = static_cast<size_t>(p.lda);
+  // per-lane source of the staging loads: row = slab*RPI + lane/LPR, chunk swizzled by
+  // the row (for 128-byte rows the swizzle depends on the slab's parity = wave&1,
+  // because every wave takes slabs wave, wave+NW, ... and NW is even)
+  //
+  // Addressing: buffer loads (buffer_load_dwordx4 ... offen lds) with one descriptor per
+  // operand tile, ONE per-lane VGPR offset (row-in-slab * stride + swizzled chunk) and a
+  // scalar offset for slab + k-step.  Flat per-load 64-bit addresses cost two VGPRs per
+  // load; at 256 VGPRs the compiler spilled them and each scratch reload drained the
+  // whole LDS-DMA queue (s_waitcnt vmcnt(0)) inside the k-loop.
+  const int srow = lane / Cfg::LPR;
+  const int schunk = ((lane % Cfg::LPR) ^ swz<BK>(wave * Cfg::RPI + srow)) << 4;
+  const int voff_w = srow * p.ldw + schunk;
+  const int voff_a = srow * p.lda + schunk;
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int8_t *>(p.w + static_cast<size_t>(m0) * ldw), 0, G_BM * p.ldw, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int8_t *>(p.a + static_cast<size_t>(f0) * lda), 0, FT * p.lda, 0x00020000);
+
+  const int KT = p.K / BK;
+  auto stage = [&](int kt, int buf) {
+    char *base = smem + buf * Cfg::STAGE;
+    const int koff = kt * BK;
+#pragma unroll
+    for (int s = 0; s < Cfg::W_SLABS / NW; ++s)  // weight slabs wave, wave+NW, ...
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, FDNN_LDS_PTR(base + (s * NW + wave) * 1024), 16, voff_w,
+                                               (s * NW + wave) * Cfg::RPI * p.ldw + koff, 0, 0);
+#pragma unroll
+    for (int s = 0; s < (Cfg::A_SLABS + NW - 1) / NW; ++s) {  // activation slabs wave, wave+NW, ...
+      if (Cfg::A_SLABS % NW == 0 || s * NW + wave < Cfg::A_SLABS)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, FDNN_LDS_PTR(base + Cfg::W_BYTES + (s * NW + wave) * 1024), 16,
+                                                 voff_a, (s * NW + wave) * Cfg::RPI * p.lda + koff, 0, 0);
+    }
+  };
+
+  v16i acc[2][NF];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < NF; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < KT) stage(s, s);
+
+  const int frow = lane & 31, fch = lane >> 5;
+  const int arow0 = wn * 32 * NF;  // this wave's first frame row inside the tile
+
+  // pmaddubsw saturation (dnn.cc:337-340).  The MFMA sum is exact; the reference
+  // saturates every ADJACENT pair a[2j]*w[2j] + a[2j+1]*w[2j+1] to int16.  Only the
+  // few (node, pair) entries listed at load time can saturate at all.  Those of this
+  // wave's 64 nodes are sorted by k; when the k-step holding an entry's columns is in
+  // LDS, the pair is recomputed from the staged activation bytes and sat16(p) - p is
+  // added to the accumulator that holds (node, frame).  The entry walk and the register
+  // select are wave-uniform; a layer without risky pairs has fix_k_next = INT_MAX.
+  //
+  // The group's first kFixCap entries are copied into LDS before the k-loop: a global
+  // load issued inside the loop returns in order BEHIND the stage's LDS-DMA loads,
+  // i.e. every entry fetched from memory would cost a whole stage latency.
+  const FixEntry *ent = reinterpret_cast<const FixEntry *>(p.fix_ent);
+  FixEntry *fix_s = reinterpret_cast<FixEntry *>(smem + Cfg::STAGE * STAGES) + wm * kFixCap;
+  int fix_e = 0, fix_e0 = 0, fix_end = 0, fix_k_next = INT_MAX;
+  FixEntry fix_cur{0, 0, 0, 0};
+  if (ent) {
+    const int grp = (m0 >> 6) + wm;
+    fix_e0 = fix_e = p.fix_grp[grp];
+    fix_end = p.fix_grp[grp + 1];
+    if (fix_e < fix_end) {
+      fix_cur = ent[fix_e];
+      fix_k_next = fix_cur.k;
+      if (wn == 0) {
+        for (int i = lane; i < min(fix_end - fix_e0, kFixCap); i += 64) fix_s[i] = ent[fix_e0 + i];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before the k-loop's first (raw) barrier
+      }
+    }
+  }
+  FDNN_TS(1);
+  // Code placement: the k-loop is sensitive to where it lands in the instruction
+  // stream (measured: the same instructions shifted by one dword ran 0.064 vs 0.049 ms
+  // per 2048x2048 layer).  Pin the loop to a 256-byte boundary so that edits elsewhere
+  // in the kernel cannot move it; FDNN_GEMM_PAD shifts it for placement experiments.
+  asm volatile(".p2align 8");
+#ifdef FDNN_GEMM_PAD
+#pragma unroll
+  for (int i = 0; i < FDNN_GEMM_PAD; ++i) asm volatile("s_nop 0");
+#endif
+
+  int buf = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+#if FDNN_GEMM_DEBUG & 64
+    if (kt == 1) FDNN_TS(2);
+#endif
+    // stage kt has landed once at most (STAGES-2) younger stages are outstanding
+    if (STAGES > 2 && kt + STAGES - 2 < KT) {
+      if (STAGES == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::MIN_LOADS) : "memory");
+      if (STAGES == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Cfg::MIN_LOADS) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // everyone's share of stage kt landed; everyone is done reading stage kt-1
+    asm volatile("" ::: "memory");
+    if (kt + STAGES - 1 < KT && !(FDNN_GEMM_DEBUG & 1)) {
+      int nb = buf + STAGES - 1;
+      if (nb >= STAGES) nb -= STAGES;
+      stage(kt + STAGES - 1, nb);
+    }
+    const char *wt = smem + buf * Cfg::STAGE;
+    const char *at = wt + Cfg::W_BYTES;
+    // Fragments are double buffered in registers: the ds_read_b128s of sub-step
+    // kk+1 are in flight while the 2*NF MFMAs of sub-step kk issue, so a wave's
+    // matrix pipe only waits for LDS once per k-step (the first sub-step).
+    v4i a[2][2], b[2][NF];
+    auto load_frags = [&](int kk, int set) {
+#if !(FDNN_GEMM_DEBUG & 4)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[set][mi] = read_frag<BK>(wt, 64 * wm + 32 * mi + frow, kk * 2 + fch);
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) b[set][ni] = read_frag<BK>(at, arow0 + 32 * ni + frow, kk * 2 + fch);
+#else
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) a[set][mi] = v4i{kt, kk, mi, lane};
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) b[set][ni] = v4i{kt, kk, ni, lane};
+#endif
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      if (kk + 1 < BK / 32) load_frags(kk + 1, (kk + 1) & 1);
+#if !(FDNN_GEMM_DEBUG & 2)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+          acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kk & 1][mi], b[kk & 1][ni], acc[mi][ni], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+#else
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) asm volatile("" ::"v"(a[kk & 1][mi]), "v"(b[kk & 1][ni]));
+#endif
+    }
+    while (fix_k_next < (kt + 1) * BK) {  // rare: a risky pair lives in this k-step
+      const FixEntry t = fix_cur;  // fetched when the previous entry was consumed
+      const int node = __builtin_amdgcn_readfirstlane(t.node) - (m0 + 64 * wm);  // 0..63
+      const int kl = __builtin_amdgcn_readfirstlane(t.k) - kt * BK;              // even, 0..BK-2
+      const int w0 = __builtin_amdgcn_readfirstlane(t.w0), w1 = __builtin_amdgcn_readfirstlane(t.w1);
+      const int rr = node & 31;
+      const int idx = (node >> 5) * 16 + (rr & 3) + 4 * (rr >> 3);  // mi*16 + reg
+      const bool mine = (lane >> 5) == ((rr >> 2) & 1);
+      int c[NF];
+      uint32_t pair[NF];
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) {  // all lanes read (no divergent branch): the NF gathers go out together
+        const int row = arow0 + 32 * ni + frow;
+        pair[ni] = *reinterpret_cast<const uint16_t *>(at + row * BK + (((kl >> 4) ^ swz<BK>(row)) << 4) + (kl & 15));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) asm volatile("" : "+v"(pair[ni]));
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) {
+        const int a0 = static_cast<int>((pair[ni] & 0xff) ^ 0x80), a1 = static_cast<int>((pair[ni] >> 8) ^ 0x80);  // back to u8
+        const int prod = a0 * w0 + a1 * w1;
+        c[ni] = mine ? max(-32768, min(32767, prod)) - prod : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        if (idx == i) {
+#pragma unroll
+          for (int ni = 0; ni < NF; ++ni) acc[i >> 4][ni][i & 15] += c[ni];
+        }
+      }
+      ++fix_e;
+      if (fix_e < fix_end) {
+        fix_cur = (fix_e - fix_e0 < kFixCap) ? fix_s[fix_e - fix_e0] : ent[fix_e];  // LDS copy; global only past the cap
+        fix_k_next = __builtin_amdgcn_readfirstlane(fix_cur.k);
+      } else {
+        fix_k_next = INT_MAX;
+      }
+    }
+    if (++buf == STAGES) buf = 0;
+  }
+
+  // ------------------------------------------------------------ epilogue
+  FDNN_TS(3);
+  // the ring is free now: drop the sigmoid table into LDS
+  uint8_t *lut = reinterpret_cast<uint8_t *>(smem);
+  // ... and this tile's 256 biases and 128*sum(w) offsets.  They must not be fetched
+  // from global memory between the stores below: vmcnt also counts stores, so every
+  // such load would wait for all earlier stores of the wave to be acknowledged.
+  float *bias_s = reinterpret_cast<float *>(smem + 3072);
+  int *wsum_s = reinterpret_cast<int *>(smem + 3072 + 4 * G_BM);
+  char *tile_s = smem + 8192;  // hidden layers: s8 output tile [FT][kTS]
+  constexpr int kTS = G_BM + 16;  // row stride: 16-byte aligned, rows 16 apart share a bank (2-way at worst)
+  __syncthreads();
+  if (!OUTPUT) {
+    if (FAST) {  // half-step table, 2563 bytes moved as dwords
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(p.lut2);
+      for (int i = tid; i < (kLut2Size + 3) / 4; i += Cfg::THREADS) reinterpret_cast<uint32_t *>(lut)[i] = src[i];
+    } else {
+      for (int i = tid; i < kLutExt; i += Cfg::THREADS) lut[i] = p.lut[i];
+    }
+  }
+  if (tid < G_BM) {
+    bias_s[tid] = p.bias[m0 + tid];
+    wsum_s[tid] = p.wsum[m0 + tid];
+  }
+  __syncthreads();
+  FDNN_TS(4);
+  // D layout (32x32): column (frame) = lane&31, row (node) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  const int half = lane >> 5;
+  const bool vec4 = (p.rows & 3) == 0;
+  const int fw0 = f0 + arow0;
+
+  float psum[NF];
+#pragma unroll
+  for (int ni = 0; ni < NF; ++ni) psum[ni] = 0.0f;
+#if FDNN_GEMM_DEBUG & 32
+  {  // timing experiment: no epilogue at all (keep the accumulators alive)
+    int keep = 0;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep ^= acc[mi][ni][r];
+    if (keep == 0x12345678) p.act_out[0] = 1;
+    return;
+  }
+#endif
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nb = m0 + 64 * wm + 32 * mi + 8 * g + 4 * half;  // 4 consecutive nodes nb..nb+3
+      const float4 b4 = *reinterpret_cast<const float4 *>(bias_s + (nb - m0));
+      const int4 ws4 = *reinterpret_cast<const int4 *>(wsum_s + (nb - m0));
+      const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
+      const int wj[4] = {ws4.x, ws4.y, ws4.z, ws4.w};
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) {
+        const int f = fw0 + 32 * ni + frow;
+        int av[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          av[q] = acc[mi][ni][g * 4 + q] + wj[q];
+          if (TAP && f < p.n && nb + q < p.rows) p.tap_acc[static_cast<size_t>(f) * p.rows + nb + q] = av[q];
+        }
+        if (!OUTPUT) {
+          // AddBias + QuantizedSigmoid: four table indices first, then the four LDS
+          // byte gathers together (one wait), then one packed dword store
+          int idx[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float lin = dequant<FAST>(av[q], p.coef, p.rcp_coef) + bj[q];
+            if (FAST) {
+              // RN(lin*200) = 2*RN(lin*100) exactly; trunc -> half-step index (see fdnn_model.cpp)
+              const int u = static_cast<int>(lin * 200.0f);
+              idx[q] = max(-kLut2Half, min(kLut2Half, u)) + kLut2Half;
+            } else {
+              idx[q] = lut_index(lin);
+            }
+          }
+          uint32_t packed = 0;
+#if FDNN_GEMM_DEBUG & 8
+#pragma unroll
+          for (int q = 0; q < 4; ++q) packed |= static_cast<uint32_t>(idx[q] & 0xff) << (8 * q);
+#else
+#pragma unroll
+          for (int q = 0; q < 4; ++q) packed |= static_cast<uint32_t>(lut[idx[q]]) << (8 * q);
+#endif
+          // Park the four bytes in the LDS image of the output tile ([frame][256 nodes],
+          // row stride kTS); the tile leaves as whole 256-byte rows below.  A direct
+          // dword store would touch 32 different rows (8 bytes each) per wave
+          // instruction and is address-processing bound.
+          *reinterpret_cast<uint32_t *>(tile_s + (arow0 + 32 * ni + frow) * kTS + (nb - m0)) = packed;
+        } else {
+          float e[4];
+          const bool live = f < p.n;
+          uint32_t mbits = 0x01010101u;
+          if (p.mask && live && nb < p.rows) {
+            const int8_t *mp = p.mask + static_cast<size_t>(f) * p.rows + nb;
+            if (vec4) {
+              mbits = *reinterpret_cast<const uint32_t *>(mp);
+            } else {
+              mbits = 0;
+              for (int q = 0; q < 4; ++q)
+                if (nb + q < p.rows && mp[q]) mbits |= 0xffu << (8 * q);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            // sum/coef, then += bias (dnn.cc:311, :446); masked-out nodes keep z = 0 (dnn.cc:366-369)
+            float z = dequant<FAST>(av[q], p.coef, p.rcp_coef) + bj[q];
+            if (((mbits >> (8 * q)) & 0xffu) == 0) z = 0.0f;
+            if (TAP && live && nb + q < p.rows) p.tap_logit[static_cast<size_t>(f) * p.rows + nb + q] = z;
+            e[q] = (nb + q < p.rows) ? expf(z) : 0.0f;
+            psum[ni] += e[q];
+          }
+          if (live) {
+            float *op = p.out + static_cast<size_t>(f) * p.rows + nb;
+            if (vec4) {
+              if (nb < p.rows) *reinterpret_cast<float4 *>(op) = make_float4(e[0], e[1], e[2], e[3]);
+            } else {
+              for (int q = 0; q < 4; ++q)
+                if (nb + q < p.rows) op[q] = e[q];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!OUTPUT) {
+    // the s8 activation tile: FT rows x 256 bytes, written as 16 bytes per lane
+    __syncthreads();
+    for (int item = tid; item < FT * 16; item += Cfg::THREADS) {
+      const int row = item >> 4, ch = item & 15;
+      const uint4 v = *reinterpret_cast<const uint4 *>(tile_s + row * kTS + ch * 16);
+#if FDNN_GEMM_DEBUG & 16
+      if (v.x == 0x12345678u && row == -7)
+#else
+      if (m0 + ch * 16 < p.rows)  // rows is a multiple of 16
+#endif
+        *reinterpret_cast<uint4 *>(p.act_out + static_cast<size_t>(f0 + row) * p.act_ld + m0 + ch * 16) = v;
+    }
+  }
+  if (OUTPUT) {
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni) {
+      const float tot = psum[ni] + __shfl_xor(psum[ni], 32);
+      const int f = fw0 + 32 * ni + frow;
+      if (half == 0) p.partial[static_cast<size_t>(mt * 4 + wm) * p.partial_ld + f] = tot;
+    }
+  }
+#if FDNN_GEMM_DEBUG & 64
+  FDNN_TS(5);
+  const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+#if FDNN_GEMM_DEBUG & 128
+  if (!OUTPUT && tid == 0) printf("B %d %llu %llu\n", blockIdx.x, rt0, rt1);
+#else
+  if (!OUTPUT && tid == 0 && (blockIdx.x % 37) == 0)
+#endif
+#if !(FDNN_GEMM_DEBUG & 128)
+    printf("blk %4d  rt0 %llu rt1 %llu | prologue %6lld  first-stage %6lld  mainloop %7lld  lut %6lld  epilogue %7lld  total %7lld cyc\n",
+           blockIdx.x, rt0, rt1, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[5] - ts[0]);
+#endif
+#endif
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool FAST = true>
+void launch_cfg(const QGemmParams &p, hipStream_t s) {
+  using Cfg = GemmCfg<NF, WN, BK, STAGES>;
+  const int MT = p.rows_pad / G_BM, NT = p.n_pad / Cfg::FT;
+  const int blocks = 8 * MT * ((NT + 7) / 8);
+  auto k_prod = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST>;
+  auto k_tap = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, true, FAST>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_prod), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_tap), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    attr_set = true;
+  }
+  if (p.tap_acc)
+    hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+  else
+    hipLaunchKernelGGL(k_prod, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+}
+
+template <bool OUTPUT>
+void launch_qgemm(const QGemmParams &p, hipStream_t s) {
+  if (!p.fastdiv) {  // layer whose coefficient failed the exact-division check (e.g. 127/0 = inf)
+    launch_cfg<4, 1, 64, 3, OUTPUT, false>(p, s);
+    return;
+  }
+  switch (p.frame_tile) {
+    // 4 waves, 64-byte k-step, 3-stage ring, two workgroups per CU
+    case 128: launch_cfg<4, 1, 64, 3, OUTPUT>(p, s); break;
+    case 160: launch_cfg<5, 1, 64, 3, OUTPUT>(p, s); break;
+    // 8 waves, 128-byte k-step (whole cache lines), double buffer, one workgroup per CU
+    case 256: launch_cfg<4, 2, 128, 2, OUTPUT>(p, s); break;
+    default: launch_cfg<5, 2, 128, 2, OUTPUT>(p, s); break;  // 320
+  }
+}
+
+}  // namespace
+
+int qgemm_debug_flags() {
+  static const int flags = [] {
+    const char *e = std::getenv("FDNN_GEMM_DEBUG");
+    return e ? std::atoi(e) : 0;
+  }();
+  return flags;
+}
+
+int qgemm_frame_tile(int rows_pad, int n) {
+  static const int forced = [] {
+    const char *e = std::getenv("FDNN_FRAME_TILE");
+    return e ? std::atoi(e) : 0;
+  }();
+  if (forced == 128 || forced == 160 || forced == 256 || forced == 320) return forced;
+  // Cost model: rounds x frames per tile / relative throughput of the kernel shape.
+  // A round fills every CU once (two co-resident workgroups for the 4-wave shapes).
+  const int mt = rows_pad / G_BM;
+  struct Cand {
+    int ft, slots;
+    double eff;
+  };
+  const Cand cands[] = {{128, 512, 0.55}, {160, 512, 0.55}, {256, 256, 1.0}, {320, 256, 1.0}};
+  int best = 128;
+  double best_cost = -1.0;
+  for (const Cand &c : cands) {
+    const long blocks = static_cast<long>(mt) * ((n + c.ft - 1) / c.ft);
+    const long rounds = (blocks + c.slots - 1) / c.slots;
+    // a 4-wave workgroup shares its CU with a second one: a round costs two tiles' time
+    const double cost = rounds * c.ft * (c.slots == 512 ? 2.0 : 1.0) / c.eff;
+    if (best_cost < 0 || cost < best_cost || (cost == best_cost && c.ft > best)) {
+      best_cost = cost;
+      best = c.ft;
+    }
+  }
+  return best;
+}
+
+void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s) { launch_qgemm<false>(p, s); }
+void launch_qgemm_output(const QGemmParams &p, hipStream_t s) { launch_qgemm<true>(p, s); }
+
+}  // namespace fdnn

@@ -6,7 +6,7 @@
 
 namespace fdnn {
 
-constexpr int kMaxFrameTile = 192;  // largest GEMM frame tile; scratch rows carry this much slack
+constexpr int kMaxFrameTile = 320;  // largest GEMM frame tile; scratch rows carry this much slack
 constexpr int kPartialNodes = 64;   // nodes covered by one soft-max partial sum
 
 // Layer 0: shift/scale + fp32 affine + bias + sigmoid LUT -> s8 activations.
@@ -29,6 +29,7 @@ void launch_l0(const L0Params &p, hipStream_t s);
 // Frame tile (128/160/192) the int8 GEMM should use for `n` frames of a layer
 // with rows_pad padded nodes; n_pad = n rounded up to it.
 int qgemm_frame_tile(int rows_pad, int n);
+int qgemm_debug_flags();
 
 // int8 layer: C[node][frame] = sum_k W[node][k] * (A[frame][k] + 128), then the
 // layer's epilogue.  W rows are padded to 256, A rows to the frame tile.
@@ -40,9 +41,11 @@ struct QGemmParams {
   const int32_t *fix_grp; // [rows_pad/64 + 1] entry range of every 64-node group
   const void *fix_ent;    // FixEntry[n_fix] sorted by node; null when the layer has no risky pairs
   const uint8_t *lut;     // [kLutExt]
+  const uint8_t *lut2;    // [kLut2Size] half-step table (fast epilogue)
   int rows, rows_pad, K, n, n_pad;
   int ldw, lda;           // row strides (bytes) of w and a: K plus the anti-channel-conflict skew
-  int frame_tile;         // 128 / 160 / 192, n_pad is a multiple of it
+  int frame_tile;         // 128 / 160 / 192 / 256 / 320, n_pad is a multiple of it
+  int debug;              // timing experiments only (FDNN_GEMM_DEBUG): 1 no staging, 2 no MFMA, 4 no LDS reads
   float coef, rcp_coef;
   int fastdiv;
   // hidden-layer output

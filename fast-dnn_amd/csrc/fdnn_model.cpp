@@ -202,6 +202,7 @@ int pack(const std::vector<RawLayer> &layers, const std::vector<float> &shift, c
   h.off_shift = place(sizeof(float) * size_t(D));
   h.off_scale = place(sizeof(float) * size_t(D));
   h.off_lut = place(size_t(kLutExt) + 15);
+  h.off_lut2 = place(size_t(kLut2Size) + 15);
   for (int qi = 0; qi < h.n_q; ++qi) {
     const RawLayer &L = layers[size_t(qi) + 1];
     QTmp &t = qt[size_t(qi)];
@@ -238,6 +239,32 @@ int pack(const std::vector<RawLayer> &layers, const std::vector<float> &shift, c
     ext[0] = 0 ^ 0x80;
     for (int i = 1; i < kLutSize; ++i) ext[i] = lut[i] ^ 0x80;
     ext[kLutSize] = 255 ^ 0x80;
+    // Half-step table for the int8-layer epilogue.  k = (int)round(t) (half away from
+    // zero) equals sign(u) * ((|u| + 1) >> 1) with u = trunc(2t), and 2t = RN(lin*200)
+    // exactly, so QuantizedSigmoid::get(lin) = table2[clamp(u, -kLut2Half, kLut2Half)]:
+    // one multiply, one convert, one clamp, one byte gather.
+    uint8_t *t2 = b + h.off_lut2;
+    for (int u = -kLut2Half; u <= kLut2Half; ++u) {
+      const int mag = ((u < 0 ? -u : u) + 1) >> 1;
+      const int k = u < 0 ? -mag : mag;
+      const uint8_t v = k <= -kLutHalf ? 0 : (k >= kLutHalf ? 255 : lut[k + kLutHalf]);  // dnn.h:38-42
+      t2[u + kLut2Half] = v ^ 0x80;
+    }
+  }
+  // The half-step table path converts lin*200 to int32: valid when no |lin| can reach
+  // 2^31/200 (the x86 build would turn such values into INT_MIN -> 0, dnn.h:37) and no
+  // bias is NaN/inf.  |acc| <= cols*255*128, so bound |lin| per layer.
+  for (int qi = 0; qi < h.n_q; ++qi) {
+    const RawLayer &L = layers[size_t(qi) + 1];
+    QLayerDesc &d = h.q[qi];
+    float bmax = 0.0f;
+    bool finite = std::isfinite(d.coef) && d.coef > 0.0f;
+    for (float bv : L.bias) {
+      if (!std::isfinite(bv)) finite = false;
+      bmax = std::max(bmax, std::fabs(bv));
+    }
+    const double bound = finite ? double(d.cols) * 255.0 * 128.0 / double(d.coef) + double(bmax) : 1e300;
+    d.lin_bounded = bound * 200.0 < 2.0e9 ? 1 : 0;
   }
   for (int qi = 0; qi < h.n_q; ++qi) {
     const RawLayer &L = layers[size_t(qi) + 1];

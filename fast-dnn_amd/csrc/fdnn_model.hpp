@@ -18,9 +18,11 @@ namespace fdnn {
 constexpr int kLutSize = 1280;      // dnn.h:26
 constexpr int kLutHalf = 640;       // dnn.h:27
 constexpr int kLutExt = 1281;       // device table: index clamp(k,-640,640)+640
+constexpr int kLut2Half = 1281;     // half-step table: index clamp(trunc(2t),-1281,1281)+1281
+constexpr int kLut2Size = 2 * kLut2Half + 1;
 constexpr int kMaxQLayers = 30;
 constexpr uint32_t kBlobMagic = 0x4e4e4446u;  // "FDNN"
-constexpr uint32_t kBlobVersion = 5;
+constexpr uint32_t kBlobVersion = 6;
 constexpr int kRowPad = 256;        // int8 weight rows padded to the GEMM node tile
 constexpr int kColPad = 128;        // int8 weight columns (and activation rows) padded to the GEMM k-step
 constexpr int kRowSkew = 0;         // extra bytes on int8 row strides (0: measured slower with a 64-byte skew)
@@ -43,7 +45,7 @@ struct QLayerDesc {       // lives in the blob header, read by host and device
   uint64_t off_fix_ent;   // FixEntry [n_fix], sorted by node
   int32_t rows, rows_pad, cols;
   int32_t n_fix;          // risky (node, pair) entries in this layer
-  int32_t pad0_;
+  int32_t lin_bounded;    // |sum/coef + bias| * 200 provably < 2^31 and all biases finite
   float mult;             // QuantizedSimdLayer::multiplier_
   float coef;             // mult * 255.0f  (dnn.cc:298-299)
   float rcp_coef;         // RN(1/coef) for the 3-op exact division
@@ -67,6 +69,7 @@ struct BlobHeader {
   uint64_t off_shift;     // f32 [in_dim]
   uint64_t off_scale;     // f32 [in_dim]
   uint64_t off_lut;       // u8  [kLutExt] (+pad), already XOR 0x80 (s8 activations)
+  uint64_t off_lut2;      // u8  [kLut2Size] (+pad) half-step table, XOR 0x80
   QLayerDesc q[kMaxQLayers];
 };
 

@@ -121,7 +121,8 @@ int upload_model(fdnn_model *m) {
         src = pj;
         break;
       }
-    h.q[qi].fastdiv_ok = (bad[src] == 0) ? 1 : 0;
+    // the fast epilogue = validated 3-op division + half-step table (needs bounded |lin|)
+    h.q[qi].fastdiv_ok = (bad[src] == 0 && h.q[qi].lin_bounded) ? 1 : 0;
   }
   std::memcpy(m->hm.blob.data(), &h, sizeof(h));
   HIP_TRY(hipMemcpy(m->d_blob, m->hm.blob.data(), m->hm.blob.size(), hipMemcpyHostToDevice));
@@ -231,7 +232,8 @@ fdnn::QGemmParams prepare_qlayer(fdnn_ctx *c, const QLayerDesc &d, const int8_t 
   const BlobHeader &h = m->hm.hdr;
   const uint8_t *B = m->d_blob;
   fdnn::QGemmParams g{};
-  g.frame_tile = fdnn::qgemm_frame_tile(d.rows_pad, n);
+  g.frame_tile = d.fastdiv_ok ? fdnn::qgemm_frame_tile(d.rows_pad, n) : 128;  // the true-divide kernel has one shape
+  g.debug = fdnn::qgemm_debug_flags();
   g.n = n;
   g.n_pad = round_up(n, g.frame_tile);
   if (d.n_fix > 0) {
@@ -243,6 +245,7 @@ fdnn::QGemmParams prepare_qlayer(fdnn_ctx *c, const QLayerDesc &d, const int8_t 
   g.bias = reinterpret_cast<const float *>(B + d.off_bias);
   g.wsum = reinterpret_cast<const int32_t *>(B + d.off_wsum);
   g.lut = B + h.off_lut;
+  g.lut2 = B + h.off_lut2;
   g.rows = d.rows;
   g.rows_pad = d.rows_pad;
   g.K = d.cols_pad - fdnn::kRowSkew;
