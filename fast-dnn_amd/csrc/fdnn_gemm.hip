@@ -223,6 +223,61 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     }
     const char *wt = smem + buf * Cfg::STAGE;
     const char *at = wt + Cfg::W_BYTES;
+#if FDNN_GEMM_DEBUG & 64
+    const long long tf0 = __builtin_readcyclecounter();
+    const int fe0 = fix_e;
+#endif
+    while (fix_k_next < (kt + 1) * BK) {  // rare: a risky pair lives in this k-step
+      const FixEntry t = fix_cur;  // fetched when the previous entry was consumed
+      const int node = __builtin_amdgcn_readfirstlane(t.node) - (m0 + 64 * wm);  // 0..63
+      const int kl = __builtin_amdgcn_readfirstlane(t.k) - kt * BK;              // even, 0..BK-2
+      const int w0 = __builtin_amdgcn_readfirstlane(t.w0), w1 = __builtin_amdgcn_readfirstlane(t.w1);
+      const int rr = node & 31;
+      const int idx = (node >> 5) * 16 + (rr & 3) + 4 * (rr >> 3);  // mi*16 + reg
+      const bool mine = (lane >> 5) == ((rr >> 2) & 1);
+      int c[NF];
+      uint32_t pair[NF];
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) {  // all lanes read (no divergent branch): the NF gathers go out together
+        const int row = arow0 + 32 * ni + frow;
+        pair[ni] = *reinterpret_cast<const uint16_t *>(at + row * BK + (((kl >> 4) ^ swz<BK>(row)) << 4) + (kl & 15));
+      }
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) asm volatile("" : "+v"(pair[ni]));
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) {
+        const int a0 = static_cast<int>((pair[ni] & 0xff) ^ 0x80), a1 = static_cast<int>((pair[ni] >> 8) ^ 0x80);  // back to u8
+        const int prod = a0 * w0 + a1 * w1;
+        c[ni] = mine ? max(-32768, min(32767, prod)) - prod : 0;
+      }
+      // saturation actually firing is rare (both activations of the pair must be near
+      // 255): skip the register select when no lane has a non-zero correction
+      int nz = 0;
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) nz |= c[ni];
+      if (__ballot(nz != 0) != 0ull) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+          if (idx == i) {
+#pragma unroll
+            for (int ni = 0; ni < NF; ++ni) acc[i >> 4][ni][i & 15] += c[ni];
+          }
+        }
+      }
+      ++fix_e;
+      if (fix_e < fix_end) {
+        fix_cur = (fix_e - fix_e0 < kFixCap) ? fix_s[fix_e - fix_e0] : ent[fix_e];  // LDS copy; global only past the cap
+        fix_k_next = __builtin_amdgcn_readfirstlane(fix_cur.k);
+      } else {
+        fix_k_next = INT_MAX;
+      }
+    }
+#if FDNN_GEMM_DEBUG & 64
+    if (fix_e != fe0) {
+      ts_fix += __builtin_readcyclecounter() - tf0;
+      n_fix_done += fix_e - fe0;
+    }
+#endif
     // Fragments are double buffered in registers: the ds_read_b128s of sub-step
     // kk+1 are in flight while the 2*NF MFMAs of sub-step kk issue, so a wave's
     // matrix pipe only waits for LDS once per k-step (the first sub-step).
@@ -258,44 +313,6 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) asm volatile("" ::"v"(a[kk & 1][mi]), "v"(b[kk & 1][ni]));
 #endif
-    }
-    while (fix_k_next < (kt + 1) * BK) {  // rare: a risky pair lives in this k-step
-      const FixEntry t = fix_cur;  // fetched when the previous entry was consumed
-      const int node = __builtin_amdgcn_readfirstlane(t.node) - (m0 + 64 * wm);  // 0..63
-      const int kl = __builtin_amdgcn_readfirstlane(t.k) - kt * BK;              // even, 0..BK-2
-      const int w0 = __builtin_amdgcn_readfirstlane(t.w0), w1 = __builtin_amdgcn_readfirstlane(t.w1);
-      const int rr = node & 31;
-      const int idx = (node >> 5) * 16 + (rr & 3) + 4 * (rr >> 3);  // mi*16 + reg
-      const bool mine = (lane >> 5) == ((rr >> 2) & 1);
-      int c[NF];
-      uint32_t pair[NF];
-#pragma unroll
-      for (int ni = 0; ni < NF; ++ni) {  // all lanes read (no divergent branch): the NF gathers go out together
-        const int row = arow0 + 32 * ni + frow;
-        pair[ni] = *reinterpret_cast<const uint16_t *>(at + row * BK + (((kl >> 4) ^ swz<BK>(row)) << 4) + (kl & 15));
-      }
-#pragma unroll
-      for (int ni = 0; ni < NF; ++ni) asm volatile("" : "+v"(pair[ni]));
-#pragma unroll
-      for (int ni = 0; ni < NF; ++ni) {
-        const int a0 = static_cast<int>((pair[ni] & 0xff) ^ 0x80), a1 = static_cast<int>((pair[ni] >> 8) ^ 0x80);  // back to u8
-        const int prod = a0 * w0 + a1 * w1;
-        c[ni] = mine ? max(-32768, min(32767, prod)) - prod : 0;
-      }
-#pragma unroll
-      for (int i = 0; i < 32; ++i) {
-        if (idx == i) {
-#pragma unroll
-          for (int ni = 0; ni < NF; ++ni) acc[i >> 4][ni][i & 15] += c[ni];
-        }
-      }
-      ++fix_e;
-      if (fix_e < fix_end) {
-        fix_cur = (fix_e - fix_e0 < kFixCap) ? fix_s[fix_e - fix_e0] : ent[fix_e];  // LDS copy; global only past the cap
-        fix_k_next = __builtin_amdgcn_readfirstlane(fix_cur.k);
-      } else {
-        fix_k_next = INT_MAX;
-      }
     }
     if (++buf == STAGES) buf = 0;
   }
@@ -347,8 +364,74 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     return;
   }
 #endif
+  if (OUTPUT) {
+    // CalculateOutput / LazyOutputActivations: z = sum/coef + bias (masked-out nodes keep
+    // z = 0, dnn.cc:366-369), e = exp(z) (SoftMax::apply first loop, dnn.cc:536-540).
+    // Each wave parks one 64-node x 32-frame block of e in its own LDS tile and writes
+    // it out as 256-byte row segments (a direct float4 store per accumulator group
+    // would touch 32 rows x 32 bytes per instruction and is address-processing bound).
+    constexpr int kOS = 64 + 4;  // floats per tile row
+    float *wtile = reinterpret_cast<float *>(smem + 8192) + wave * (32 * kOS);
+    const int ncol0 = m0 + 64 * wm;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
+    for (int ni = 0; ni < NF; ++ni) {
+      const int f = fw0 + 32 * ni + frow;
+      const bool live = f < p.n;
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = ncol0 + 32 * mi + 8 * g + 4 * half;  // 4 consecutive nodes nb..nb+3
+          const float4 b4 = *reinterpret_cast<const float4 *>(bias_s + (nb - m0));
+          const int4 ws4 = *reinterpret_cast<const int4 *>(wsum_s + (nb - m0));
+          const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
+          const int wj[4] = {ws4.x, ws4.y, ws4.z, ws4.w};
+          uint32_t mbits = 0x01010101u;
+          if (p.mask && live && nb < p.rows) {
+            const int8_t *mp = p.mask + static_cast<size_t>(f) * p.rows + nb;
+            if (vec4) {
+              mbits = *reinterpret_cast<const uint32_t *>(mp);
+            } else {
+              mbits = 0;
+              for (int q = 0; q < 4; ++q)
+                if (nb + q < p.rows && mp[q]) mbits |= 0xffu << (8 * q);
+            }
+          }
+          float e[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int av = acc[mi][ni][g * 4 + q] + wj[q];
+            if (TAP && live && nb + q < p.rows) p.tap_acc[static_cast<size_t>(f) * p.rows + nb + q] = av;
+            float z = dequant<FAST>(av, p.coef, p.rcp_coef) + bj[q];  // sum/coef, then += bias (dnn.cc:311, :446)
+            if (((mbits >> (8 * q)) & 0xffu) == 0) z = 0.0f;
+            if (TAP && live && nb + q < p.rows) p.tap_logit[static_cast<size_t>(f) * p.rows + nb + q] = z;
+            e[q] = (nb + q < p.rows) ? __expf(z) : 0.0f;
+            psum[ni] += e[q];
+          }
+          *reinterpret_cast<float4 *>(wtile + frow * kOS + (nb - ncol0)) = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+      // wave-private tile: 8 x (4 rows x 256 B) stores
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = r * 4 + (lane >> 4), col = (lane & 15) * 4;
+        const float4 v = *reinterpret_cast<const float4 *>(wtile + row * kOS + col);
+        const int ff = fw0 + 32 * ni + row;
+        if (ff < p.n) {
+          float *op = p.out + static_cast<size_t>(ff) * p.rows + ncol0 + col;
+          if (vec4) {
+            if (ncol0 + col < p.rows) *reinterpret_cast<float4 *>(op) = v;
+          } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            for (int q = 0; q < 4; ++q)
+              if (ncol0 + col + q < p.rows) op[q] = vv[q];
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < (OUTPUT ? 0 : 2); ++mi) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nb = m0 + 64 * wm + 32 * mi + 8 * g + 4 * half;  // 4 consecutive nodes nb..nb+3
@@ -365,7 +448,7 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
           av[q] = acc[mi][ni][g * 4 + q] + wj[q];
           if (TAP && f < p.n && nb + q < p.rows) p.tap_acc[static_cast<size_t>(f) * p.rows + nb + q] = av[q];
         }
-        if (!OUTPUT) {
+        {
           // AddBias + QuantizedSigmoid: four table indices first, then the four LDS
           // byte gathers together (one wait), then one packed dword store
           int idx[4];
@@ -393,38 +476,6 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
           // dword store would touch 32 different rows (8 bytes each) per wave
           // instruction and is address-processing bound.
           *reinterpret_cast<uint32_t *>(tile_s + (arow0 + 32 * ni + frow) * kTS + (nb - m0)) = packed;
-        } else {
-          float e[4];
-          const bool live = f < p.n;
-          uint32_t mbits = 0x01010101u;
-          if (p.mask && live && nb < p.rows) {
-            const int8_t *mp = p.mask + static_cast<size_t>(f) * p.rows + nb;
-            if (vec4) {
-              mbits = *reinterpret_cast<const uint32_t *>(mp);
-            } else {
-              mbits = 0;
-              for (int q = 0; q < 4; ++q)
-                if (nb + q < p.rows && mp[q]) mbits |= 0xffu << (8 * q);
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            // sum/coef, then += bias (dnn.cc:311, :446); masked-out nodes keep z = 0 (dnn.cc:366-369)
-            float z = dequant<FAST>(av[q], p.coef, p.rcp_coef) + bj[q];
-            if (((mbits >> (8 * q)) & 0xffu) == 0) z = 0.0f;
-            if (TAP && live && nb + q < p.rows) p.tap_logit[static_cast<size_t>(f) * p.rows + nb + q] = z;
-            e[q] = (nb + q < p.rows) ? expf(z) : 0.0f;
-            psum[ni] += e[q];
-          }
-          if (live) {
-            float *op = p.out + static_cast<size_t>(f) * p.rows + nb;
-            if (vec4) {
-              if (nb < p.rows) *reinterpret_cast<float4 *>(op) = make_float4(e[0], e[1], e[2], e[3]);
-            } else {
-              for (int q = 0; q < 4; ++q)
-                if (nb + q < p.rows) op[q] = e[q];
-            }
-          }
         }
       }
     }
