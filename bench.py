@@ -145,6 +145,17 @@ def main() -> None:
     prof = dnn.profileEnd()
 
     if rank == 0:
+        # HBM-side bytes per launch of the dominant kernel come from the committed PMC passes
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as the
+        # gfx950 guide prescribes); bench.py itself cannot run under rocprof.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            for name, c in pm.items():
+                if name.startswith("qgemm_kernel hidden") and n == FRAMES_PER_GPU:
+                    traffic = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1000)  # bytes per launch
+        except Exception:
+            traffic = None
         hid = prof["hidden_gemm"]
         hid_ms = hid["ms"] / max(hid["launches"], 1)
         achieved = HIDDEN_OPS_PER_FRAME * n / (hid_ms * 1e-3) / 1e12
@@ -172,7 +183,9 @@ def main() -> None:
             "roofline": {
                 "kernel": "qgemm_kernel<hidden> (int8 MFMA 2048x2048 layer + dequant/bias/sigmoid-LUT epilogue)",
                 "bound": "mfma", "achieved": round(achieved, 1), "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
-                "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": None,
+                "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM+MALL bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_summary.json)",
+                "algorithmic_bytes_per_launch": 2048 * 2048 + 2 * n * 2048,
                 "avg_launch_ms": round(hid_ms, 4), "launches": hid["launches"],
             },
             "kernel_ms_per_step": kernels_ms,

@@ -102,15 +102,17 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
   const int wm = wave & 3, wn = wave >> 2;
 
   // Workgroup b runs on XCD b%8.  Give each XCD a contiguous band of frame tiles and
-  // walk the node tiles fastest inside it: co-resident workgroups then share the
-  // same activation rows (and all of them share the weights) in that XCD's L2.
+  // walk THOSE fastest: the workgroups resident on an XCD at any time then cover all of
+  // its frame tiles (activation rows stay in its 4 MiB L2) and only a few node tiles, so
+  // every weight tile is pulled into an XCD once instead of once per frame tile (the
+  // 8000-node output layer read 548 MB per launch with node tiles fastest).
   const int MT = p.rows_pad / G_BM;
   const int NT = p.n_pad / FT;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
   const int per_xcd = (NT + 7) / 8;
-  const int mt = j % MT;
-  const int nt = xcd * per_xcd + j / MT;
-  if (j / MT >= per_xcd || nt >= NT) return;
+  const int mt = j / per_xcd;
+  const int nt = xcd * per_xcd + j % per_xcd;
+  if (mt >= MT || nt >= NT) return;
   const int m0 = mt * G_BM, f0 = nt * FT;
 
   const size_t ldw = static_cast<size_t>(p.ldw), lda = static_cast<size_t>(p.lda);
