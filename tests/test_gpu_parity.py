@@ -3,6 +3,7 @@ All calls go through the C-ABI of libfast-dnn.so (ctypes binding in
 fast_dnn_amd.api).  Integer state is compared bit-for-bit; soft-max
 probabilities to 1e-3 (BASELINE.json north_star), observed ~1e-7."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -211,3 +212,83 @@ def test_concurrent_callers_share_one_model(mid_model_path):
     for i, gp in enumerate(got):
         assert np.abs(gp - want[i % len(xs)]).max() <= TIGHT
     dnn.delete()
+
+
+def test_true_divide_variant_on_degenerate_layer(tmp_models):
+    """An all-zero int8 layer gives multiplier = round(127/0) = inf (dnn.cc:479): the
+    3-op division cannot be validated, the layer must run the IEEE-divide kernel
+    variant and still match the oracle bit for bit (0/inf = 0, then + bias)."""
+    import os
+
+    net = F.synth_net([432, 128, 128, 128, 200], seed=12)
+    net.layers[2].weights[:] = 0.0  # second int8 hidden layer
+    p = os.path.join(tmp_models, "zero_layer.bin")
+    F.write_model_bin(p, net)
+    x = F.synth_features(150, seed=6)
+    orc = Oracle(p)
+    assert np.isinf(orc.layer_mult(2))
+    want, wt = orc.calculate(x, taps=True)
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    t = dnn.forwardTaps(x)
+    assert (t["u8_acts"] == wt["u8_acts"]).all()
+    assert (t["acc_hid"] == wt["acc_hid"]).all() and (t["acc_out"] == wt["acc_out"]).all()
+    assert np.abs(t["probs"] - want).max() <= TIGHT
+    dnn.delete()
+
+
+def test_huge_bias_takes_the_exact_table_path(tmp_models):
+    """|lin|*200 may exceed 2^31 -> the half-step table shortcut is not provably valid;
+    the layer must fall back to the exact round()/INT_MIN semantics of dnn.h:36-43."""
+    import os
+
+    net = F.synth_net([432, 128, 128, 128, 200], seed=13)
+    net.layers[1].bias[::7] = 3.0e7   # (int)round(100*x) overflows int32 -> x86 gives INT_MIN -> entry 0
+    net.layers[1].bias[3::7] = -3.0e7
+    p = os.path.join(tmp_models, "huge_bias.bin")
+    F.write_model_bin(p, net)
+    x = F.synth_features(70, seed=8)
+    want, wt = Oracle(p).calculate(x, taps=True)
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    t = dnn.forwardTaps(x)
+    assert (t["u8_acts"] == wt["u8_acts"]).all()
+    assert (t["acc_out"] == wt["acc_out"]).all()
+    assert np.abs(t["probs"] - want).max() <= TIGHT
+    dnn.delete()
+
+
+@pytest.mark.parametrize("hidden", [64, 144, 272])
+def test_hidden_widths_not_multiple_of_the_k_step(tmp_models, hidden):
+    """Hidden widths are only required to be x16 (README.md:10): the k padding to 128 and
+    the 256-node tile padding must be invisible."""
+    import os
+
+    p = os.path.join(tmp_models, f"h{hidden}.bin")
+    F.write_model_bin(p, F.synth_net([432, hidden, hidden, hidden, 52], seed=20 + hidden))
+    x = F.synth_features(333, seed=9)
+    want, wt = Oracle(p).calculate(x, taps=True)
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    t = dnn.forwardTaps(x)
+    assert (t["u8_acts"] == wt["u8_acts"]).all()
+    assert (t["acc_hid"] == wt["acc_hid"]).all() and (t["acc_out"] == wt["acc_out"]).all()
+    assert np.abs(t["probs"] - want).max() <= TIGHT
+    dnn.delete()
+
+
+def test_cli_matches_oracle(tmp_path, mid_model_path, x16):
+    """fast-dnn model input out BIN|TXT (dnn.cc:20-84): big-endian input matrix, host-endian
+    u32-header BIN output, one text row per frame."""
+    import subprocess
+
+    cli = os.path.join(os.path.dirname(api.LIB_PATH), "fast-dnn")
+    inp = str(tmp_path / "in.bin")
+    F.write_feature_bin(inp, x16)
+    out_bin, out_txt = str(tmp_path / "o.bin"), str(tmp_path / "o.txt")
+    r = subprocess.run([cli, mid_model_path, inp, out_bin, "BIN"], capture_output=True, text=True, check=True)
+    assert "Network = 432-2x256-1000" in r.stdout and "Input   = 100x432" in r.stdout  # PrintTopology undercounts by one
+    subprocess.run([cli, mid_model_path, inp, out_txt, "TXT"], check=True, capture_output=True)
+    want = Oracle(mid_model_path).calculate(x16, batch=8)
+    got = F.read_output_matrix(out_bin)
+    assert got.shape == (100, 1000) and np.abs(got - want).max() <= TIGHT
+    txt = np.loadtxt(out_txt, dtype=np.float32)
+    assert txt.shape == (100, 1000) and np.abs(txt - want).max() <= 1e-5  # 6 significant digits
+    assert subprocess.run([cli, mid_model_path], capture_output=True).returncode != 0
