@@ -76,6 +76,8 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--mode", default="gauss", choices=["gauss", "nosat"], help="synthetic weight distribution")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--l0-fma", action="store_true",
+                    help="layer 0 with the fused multiply-add numerics of a -march=native reference build (fp32 MFMA)")
     args = ap.parse_args()
 
     import torch
@@ -106,6 +108,8 @@ def main() -> None:
     dnn = load_replicated(model_path, local, rank, world)
     O = dnn.outputDimension()
     n = args.frames
+    if args.l0_fma:
+        dnn.setInputLayerFma(True)
 
     x = torch.from_numpy(F.synth_features(n, 432, seed=1000 + rank)).to(dev)
     out = torch.empty((n, O), dtype=torch.float32, device=dev)
@@ -177,6 +181,7 @@ def main() -> None:
                 "workload": f"BASELINE configs[2]: synthetic Kaldi nnet 432 -> 7x2048 -> 8000 ({args.mode} weights, seed 1), "
                             f"{n}-frame batch per GPU, full soft-max, device-resident in/out",
                 "frames_per_gpu": n, "global_frames": world * n, "parallelism": f"frame-sharded x{world}, replicated weights",
+                "layer0_numerics": "fused (reference built -march=native)" if args.l0_fma else "unfused (reference built -msse4, canonical)",
             },
             "x_realtime_per_gpu": round(n * args.steps / elapsed / 100.0, 1),
             "int8_tops_end_to_end": round(INT8_OPS_PER_FRAME * n * args.steps / elapsed / 1e12, 1),

@@ -56,6 +56,29 @@ def test_tiny_fma_flavour(tiny_model_path, x16):
     dnn.delete()
 
 
+def test_fma_flavour_mfma_chains_at_scale(net_model_path):
+    """The fused flavour runs on v_mfma_f32_32x32x1_2b_f32: every one of the 4 x 2048 x n
+    fmaf chains over 108 k-quads must come out bit-identical to the CPU fmaf chains, for a
+    frame count that leaves a ragged 128-frame tile."""
+    x = F.synth_features(333, 432, seed=77)
+    Oracle.set_l0_fma(True)
+    try:
+        want, wt = Oracle(net_model_path).calculate(x, taps=True)
+    finally:
+        Oracle.set_l0_fma(False)
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    dnn.setInputLayerFma(True)
+    t = dnn.forwardTaps(x)
+    assert (t["l0_lin"] == wt["l0_lin"]).all()
+    assert (t["u8_acts"] == wt["u8_acts"]).all()
+    assert (t["acc_out"] == wt["acc_out"]).all()
+    assert np.abs(t["probs"] - want).max() <= TIGHT
+    dnn.setInputLayerFma(False)
+    t2 = dnn.forwardTaps(x)
+    assert not (t2["l0_lin"] == wt["l0_lin"]).all()  # the canonical unfused flavour differs in the last ulp
+    dnn.delete()
+
+
 def test_saturation_fixture(sat_model_path):
     """pmaddubsw pair saturation fires (dnn.cc:337-340): the sparse correction must
     reproduce the reference's int32 sums exactly."""
