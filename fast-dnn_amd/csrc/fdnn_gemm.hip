@@ -60,12 +60,16 @@ struct GemmCfg {
   static constexpr int W_SLABS = G_BM / RPI;
   static constexpr int A_SLABS = FT / RPI;
   static constexpr int MIN_LOADS = W_SLABS / NW + A_SLABS / NW;  // fewest loads any wave issues per stage
-  // after the k-loop the ring is reused for the sigmoid table (3 KiB) + biases + offsets (2 KiB)
-  // and, for hidden layers, the s8 output tile FT x (256+16) bytes.  Behind the ring:
-  // 4 node groups x kFixCap saturation-fix entries.
+  // Behind the ring: 4 node groups x kFixCap saturation-fix entries, then the sigmoid table
+  // (3 KiB window) and this tile's 256 biases, both LDS-DMA'd before the first stage so the
+  // epilogue starts without a load phase.  After the k-loop the ring is reused for the s8
+  // output tile FT x (256+16) bytes (hidden layers) / the per-wave e tiles (output layer).
   static constexpr int EPI = 8192 + FT * (G_BM + 16);
-  static constexpr int RING = STAGE * STAGES + 4 * kFixCap * 8;
+  static constexpr int FIX_OFF = STAGE * STAGES;
+  static constexpr int AUX_OFF = FIX_OFF + 4 * kFixCap * 8;  // table at +0, biases at +3072
+  static constexpr int RING = AUX_OFF + 4096;
   static constexpr int LDS = RING > EPI ? RING : EPI;
+  static_assert(EPI <= FIX_OFF, "the epilogue tile must not reach the table/biases");
   static_assert(W_SLABS % NW == 0, "weight slabs must split evenly over the waves");
   static_assert(LDS <= 160 * 1024, "LDS ring exceeds the CU");
 };
@@ -89,7 +93,8 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
   constexpr int FT = Cfg::FT, NW = Cfg::NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #if FDNN_GEMM_DEBUG & 64
-  long long ts[6];
+  long long ts[6], ts_fix = 0;
+  int n_fix_done = 0;
   const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
   ts[0] = __builtin_readcyclecounter();
 #define FDNN_TS(i) ts[i] = __builtin_readcyclecounter()
@@ -135,32 +140,63 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
       const_cast<int8_t *>(p.a + static_cast<size_t>(f0) * lda), 0, FT * p.lda, 0x00020000);
 
   const int KT = p.K / BK;
-  auto stage = [&](int kt, int buf) {
+  // one wave issues NLD 1-KB loads per stage: weight slabs wave, wave+NW, ... then activation
+  // slabs wave, wave+NW, ...
+  constexpr int NLD_W = Cfg::W_SLABS / NW, NLD = NLD_W + (Cfg::A_SLABS + NW - 1) / NW;
+  auto stage_load = [&](int kt, int buf, int i) {
     char *base = smem + buf * Cfg::STAGE;
     const int koff = kt * BK;
-#pragma unroll
-    for (int s = 0; s < Cfg::W_SLABS / NW; ++s)  // weight slabs wave, wave+NW, ...
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, FDNN_LDS_PTR(base + (s * NW + wave) * 1024), 16, voff_w,
-                                               (s * NW + wave) * Cfg::RPI * p.ldw + koff, 0, 0);
-#pragma unroll
-    for (int s = 0; s < (Cfg::A_SLABS + NW - 1) / NW; ++s) {  // activation slabs wave, wave+NW, ...
+    if (i < NLD_W) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, FDNN_LDS_PTR(base + (i * NW + wave) * 1024), 16, voff_w,
+                                               (i * NW + wave) * Cfg::RPI * p.ldw + koff, 0, 0);
+    } else {
+      const int s = i - NLD_W;
       if (Cfg::A_SLABS % NW == 0 || s * NW + wave < Cfg::A_SLABS)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, FDNN_LDS_PTR(base + Cfg::W_BYTES + (s * NW + wave) * 1024), 16,
                                                  voff_a, (s * NW + wave) * Cfg::RPI * p.lda + koff, 0, 0);
     }
   };
+  auto stage = [&](int kt, int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) stage_load(kt, buf, i);
+  };
 
+  // The epilogue's sigmoid table and biases ride the same LDS-DMA queue, ahead of the ring
+  // (older loads complete first, so every wait that covers stage 0 covers them too).
+  char *aux = smem + Cfg::AUX_OFF;
+  if (!OUTPUT && wave < 3) {
+    const int bytes = FAST ? kLut2Size : kLutExt;
+    const __amdgpu_buffer_rsrc_t rsrc_lut =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(FAST ? p.lut2 : p.lut), 0, bytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lut, FDNN_LDS_PTR(aux + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
+  }
+  if (wave == 3) {
+    const __amdgpu_buffer_rsrc_t rsrc_bias =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.bias + m0), 0, G_BM * 4, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_bias, FDNN_LDS_PTR(aux + 3072), 16, lane * 16, 0, 0, 0);
+  }
+#pragma unroll
+  for (int s = 0; s < STAGES - 1; ++s)
+    if (s < KT) stage(s, s);
+  asm volatile("" ::: "memory");  // the ring's first loads go out before anything else
+
+  // The accumulators start at 128*sum_k(w[node][k]) (the s8 = u8 - 128 activation offset),
+  // so that the epilogue has no per-output add left.  D layout (32x32): column (frame) =
+  // lane&31, row (node) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
   v16i acc[2][NF];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < NF; ++b)
+    for (int g = 0; g < 4; ++g) {
+      const int4 ws4 = *reinterpret_cast<const int4 *>(p.wsum + m0 + 64 * wm + 32 * a + 8 * g + 4 * (lane >> 5));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
-
-#pragma unroll
-  for (int s = 0; s < STAGES - 1; ++s)
-    if (s < KT) stage(s, s);
+      for (int b = 0; b < NF; ++b) {
+        acc[a][b][g * 4 + 0] = ws4.x;
+        acc[a][b][g * 4 + 1] = ws4.y;
+        acc[a][b][g * 4 + 2] = ws4.z;
+        acc[a][b][g * 4 + 3] = ws4.w;
+      }
+    }
 
   const int frow = lane & 31, fch = lane >> 5;
   const int arow0 = wn * 32 * NF;  // this wave's first frame row inside the tile
@@ -218,11 +254,17 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     }
     __builtin_amdgcn_s_barrier();  // everyone's share of stage kt landed; everyone is done reading stage kt-1
     asm volatile("" ::: "memory");
-    if (kt + STAGES - 1 < KT && !(FDNN_GEMM_DEBUG & 1)) {
-      int nb = buf + STAGES - 1;
-      if (nb >= STAGES) nb -= STAGES;
-      stage(kt + STAGES - 1, nb);
-    }
+    // The refill of the buffer freed by the barrier is NOT issued here in one burst: a wave
+    // issues in order, and NLD back-to-back LDS-DMA loads queue behind the other seven
+    // waves' loads in the CU's one address path, which keeps the wave's MFMAs waiting
+    // (tools/ubench_pipe.hip: 4550 vs 3400 cycles per 128-k step).  The loads are spread
+    // over the k sub-steps instead, each group issued just before a block of MFMAs.
+    const bool refill = kt + STAGES - 1 < KT && !(FDNN_GEMM_DEBUG & 1);
+    int nb = buf + STAGES - 1;
+    if (nb >= STAGES) nb -= STAGES;
+#ifdef FDNN_GEMM_BURST
+    if (refill) stage(kt + STAGES - 1, nb);
+#endif
     const char *wt = smem + buf * Cfg::STAGE;
     const char *at = wt + Cfg::W_BYTES;
 #if FDNN_GEMM_DEBUG & 64
@@ -301,6 +343,14 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #pragma unroll
     for (int kk = 0; kk < BK / 32; ++kk) {
       if (kk + 1 < BK / 32) load_frags(kk + 1, (kk + 1) & 1);
+#ifndef FDNN_GEMM_BURST
+      if (refill) {
+        constexpr int SUB = BK / 32;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+          if (i * SUB / NLD == kk) stage_load(kt + STAGES - 1, nb, i);
+      }
+#endif
 #if !(FDNN_GEMM_DEBUG & 2)
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -321,29 +371,14 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 
   // ------------------------------------------------------------ epilogue
   FDNN_TS(3);
-  // the ring is free now: drop the sigmoid table into LDS
-  uint8_t *lut = reinterpret_cast<uint8_t *>(smem);
-  // ... and this tile's 256 biases and 128*sum(w) offsets.  They must not be fetched
-  // from global memory between the stores below: vmcnt also counts stores, so every
-  // such load would wait for all earlier stores of the wave to be acknowledged.
-  float *bias_s = reinterpret_cast<float *>(smem + 3072);
-  int *wsum_s = reinterpret_cast<int *>(smem + 3072 + 4 * G_BM);
+  // The sigmoid table and this tile's 256 biases have been in LDS since the prologue.
+  // (They must not be fetched from global memory between the stores below: vmcnt also
+  // counts stores, so every such load would wait for all earlier stores of the wave.)
+  const uint8_t *lut = reinterpret_cast<const uint8_t *>(aux);
+  const float *bias_s = reinterpret_cast<const float *>(aux + 3072);
   char *tile_s = smem + 8192;  // hidden layers: s8 output tile [FT][kTS]
   constexpr int kTS = G_BM + 16;  // row stride: 16-byte aligned, rows 16 apart share a bank (2-way at worst)
-  __syncthreads();
-  if (!OUTPUT) {
-    if (FAST) {  // half-step table, 2563 bytes moved as dwords
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(p.lut2);
-      for (int i = tid; i < (kLut2Size + 3) / 4; i += Cfg::THREADS) reinterpret_cast<uint32_t *>(lut)[i] = src[i];
-    } else {
-      for (int i = tid; i < kLutExt; i += Cfg::THREADS) lut[i] = p.lut[i];
-    }
-  }
-  if (tid < G_BM) {
-    bias_s[tid] = p.bias[m0 + tid];
-    wsum_s[tid] = p.wsum[m0 + tid];
-  }
-  __syncthreads();
+  __syncthreads();  // every wave is done with the ring: it becomes the output tile
   FDNN_TS(4);
   // D layout (32x32): column (frame) = lane&31, row (node) = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
   const int half = lane >> 5;
@@ -385,9 +420,7 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
         for (int g = 0; g < 4; ++g) {
           const int nb = ncol0 + 32 * mi + 8 * g + 4 * half;  // 4 consecutive nodes nb..nb+3
           const float4 b4 = *reinterpret_cast<const float4 *>(bias_s + (nb - m0));
-          const int4 ws4 = *reinterpret_cast<const int4 *>(wsum_s + (nb - m0));
           const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
-          const int wj[4] = {ws4.x, ws4.y, ws4.z, ws4.w};
           uint32_t mbits = 0x01010101u;
           if (p.mask && live && nb < p.rows) {
             const int8_t *mp = p.mask + static_cast<size_t>(f) * p.rows + nb;
@@ -402,7 +435,7 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
           float e[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int av = acc[mi][ni][g * 4 + q] + wj[q];
+            const int av = acc[mi][ni][g * 4 + q];
             if (TAP && live && nb + q < p.rows) p.tap_acc[static_cast<size_t>(f) * p.rows + nb + q] = av;
             float z = dequant<FAST>(av, p.coef, p.rcp_coef) + bj[q];  // sum/coef, then += bias (dnn.cc:311, :446)
             if (((mbits >> (8 * q)) & 0xffu) == 0) z = 0.0f;
@@ -438,47 +471,44 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     for (int g = 0; g < 4; ++g) {
       const int nb = m0 + 64 * wm + 32 * mi + 8 * g + 4 * half;  // 4 consecutive nodes nb..nb+3
       const float4 b4 = *reinterpret_cast<const float4 *>(bias_s + (nb - m0));
-      const int4 ws4 = *reinterpret_cast<const int4 *>(wsum_s + (nb - m0));
       const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
-      const int wj[4] = {ws4.x, ws4.y, ws4.z, ws4.w};
+      // AddBias + QuantizedSigmoid for the 4 nodes x NF frames of this accumulator group:
+      // all 4*NF table indices first, then the 4*NF LDS byte gathers in one batch (the
+      // gathers cannot be hoisted over the tile stores by the compiler -- both live in
+      // the same LDS array -- and a wait per 4 gathers was the bulk of the epilogue).
+      uint8_t act[NF][4];
 #pragma unroll
       for (int ni = 0; ni < NF; ++ni) {
         const int f = fw0 + 32 * ni + frow;
-        int av[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          av[q] = acc[mi][ni][g * 4 + q] + wj[q];
-          if (TAP && f < p.n && nb + q < p.rows) p.tap_acc[static_cast<size_t>(f) * p.rows + nb + q] = av[q];
-        }
-        {
-          // AddBias + QuantizedSigmoid: four table indices first, then the four LDS
-          // byte gathers together (one wait), then one packed dword store
-          int idx[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float lin = dequant<FAST>(av[q], p.coef, p.rcp_coef) + bj[q];
-            if (FAST) {
-              // RN(lin*200) = 2*RN(lin*100) exactly; trunc -> half-step index (see fdnn_model.cpp)
-              const int u = static_cast<int>(lin * 200.0f);
-              idx[q] = max(-kLut2Half, min(kLut2Half, u)) + kLut2Half;
-            } else {
-              idx[q] = lut_index(lin);
-            }
+          const int av = acc[mi][ni][g * 4 + q];
+          if (TAP && f < p.n && nb + q < p.rows) p.tap_acc[static_cast<size_t>(f) * p.rows + nb + q] = av;
+          const float lin = dequant<FAST>(av, p.coef, p.rcp_coef) + bj[q];
+          int idx;
+          if (FAST) {
+            // RN(lin*200) = 2*RN(lin*100) exactly; trunc -> half-step index (see fdnn_model.cpp)
+            const int u = static_cast<int>(lin * 200.0f);
+            idx = max(-kLut2Half, min(kLut2Half, u)) + kLut2Half;
+          } else {
+            idx = lut_index(lin);
           }
-          uint32_t packed = 0;
 #if FDNN_GEMM_DEBUG & 8
-#pragma unroll
-          for (int q = 0; q < 4; ++q) packed |= static_cast<uint32_t>(idx[q] & 0xff) << (8 * q);
+          act[ni][q] = static_cast<uint8_t>(idx);
 #else
-#pragma unroll
-          for (int q = 0; q < 4; ++q) packed |= static_cast<uint32_t>(lut[idx[q]]) << (8 * q);
+          act[ni][q] = lut[idx];
 #endif
-          // Park the four bytes in the LDS image of the output tile ([frame][256 nodes],
-          // row stride kTS); the tile leaves as whole 256-byte rows below.  A direct
-          // dword store would touch 32 different rows (8 bytes each) per wave
-          // instruction and is address-processing bound.
-          *reinterpret_cast<uint32_t *>(tile_s + (arow0 + 32 * ni + frow) * kTS + (nb - m0)) = packed;
         }
+      }
+      // Park the bytes in the LDS image of the output tile ([frame][256 nodes], row stride
+      // kTS); the tile leaves as whole 256-byte rows below.  A direct dword store would
+      // touch 32 different rows (8 bytes each) per wave instruction and is
+      // address-processing bound.
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) {
+        const uint32_t packed = static_cast<uint32_t>(act[ni][0]) | static_cast<uint32_t>(act[ni][1]) << 8 |
+                                static_cast<uint32_t>(act[ni][2]) << 16 | static_cast<uint32_t>(act[ni][3]) << 24;
+        *reinterpret_cast<uint32_t *>(tile_s + (arow0 + 32 * ni + frow) * kTS + (nb - m0)) = packed;
       }
     }
   }
@@ -513,8 +543,9 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
   if (!OUTPUT && tid == 0 && (blockIdx.x % 37) == 0)
 #endif
 #if !(FDNN_GEMM_DEBUG & 128)
-    printf("blk %4d  rt0 %llu rt1 %llu | prologue %6lld  first-stage %6lld  mainloop %7lld  lut %6lld  epilogue %7lld  total %7lld cyc\n",
-           blockIdx.x, rt0, rt1, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[5] - ts[0]);
+    printf("blk %4d  rt %llu (+%llu) | prologue %6lld  first-stage %6lld  mainloop %7lld (fix %d: %lld)  lut %6lld  epilogue %7lld  total %7lld cyc\n",
+           blockIdx.x, rt0, rt1 - rt0, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], n_fix_done, ts_fix, ts[4] - ts[3], ts[5] - ts[4],
+           ts[5] - ts[0]);
 #endif
 #endif
 #endif  // __HIP_DEVICE_COMPILE__
