@@ -166,6 +166,14 @@ class LazyContext:
                                                 out.ctypes.data_as(_c_f32p)))
         return out
 
+    # device-resident forms (raw device pointers, e.g. ``tensor.data_ptr()``; enqueued on ``stream``)
+    def calculateUntilOutputDevice(self, d_input: int, stream: int = 0) -> None:
+        _check(lib().fdnn_ctx_forward_hidden_device(self.handle, C.c_void_p(d_input), C.c_void_p(stream)))
+
+    def calculateForOutputNodesBatchDevice(self, d_masks: int, d_out: int, first: int, count: int, stream: int = 0) -> None:
+        _check(lib().fdnn_ctx_lazy_output_batch_device(self.handle, first, count, C.c_void_p(d_masks), C.c_void_p(d_out),
+                                                       C.c_void_p(stream)))
+
     def hiddenActivations(self) -> np.ndarray:
         out = np.empty((self.inputVectorCount, self.dnn.hiddenDimension()), dtype=np.uint8)
         _check(lib().fdnn_ctx_read_hidden(self.handle, out.ctypes.data_as(_c_u8p)))
