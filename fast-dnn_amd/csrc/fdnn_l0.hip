@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256, TI <= 4 ? 4 : 2) void l0_valu_kernel(L0Params 
             acc[i][j][2] = fmaf(xv[i].z, wv[j].z, acc[i][j][2]);
             acc[i][j][3] = fmaf(xv[i].w, wv[j].w, acc[i][j][3]);
           } else {
+            // (grouping the four multiplies before the four adds changes nothing: 0.427 vs 0.430 ms)
             acc[i][j][0] = acc[i][j][0] + xv[i].x * wv[j].x;
             acc[i][j][1] = acc[i][j][1] + xv[i].y * wv[j].y;
             acc[i][j][2] = acc[i][j][2] + xv[i].z * wv[j].z;
