@@ -602,9 +602,13 @@ int qgemm_frame_tile(int rows_pad, int n) {
     return e ? std::atoi(e) : 0;
   }();
   if (forced == 128 || forced == 160 || forced == 256 || forced == 320) return forced;
+  const int mt = rows_pad / G_BM;
+  // Few frames: when even 128-frame tiles leave every workgroup a CU of its own, the launch
+  // is latency bound (one k-loop deep) and the smallest tile has the shortest k-step
+  // (measured per 2048x2048 layer, single round: 34 us at 128, 38 at 256, 41 at 160, 45 at 320).
+  if (static_cast<long>(mt) * ((n + 127) / 128) <= 256) return 128;
   // Cost model: rounds x frames per tile / relative throughput of the kernel shape.
   // A round fills every CU once (two co-resident workgroups for the 4-wave shapes).
-  const int mt = rows_pad / G_BM;
   struct Cand {
     int ft, slots;
     double eff;
