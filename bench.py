@@ -71,8 +71,10 @@ def cpu_baseline(model_path: str, sample_utts: int = 4, frames: int = 100):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: ~0.25 s of GPU time per pass; short runs (20 steps) read ~6 % low because the
+    # clocks are still ramping when the timed region starts
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
     ap.add_argument("--mode", default="gauss", choices=["gauss", "nosat"], help="synthetic weight distribution")
     ap.add_argument("--no-cpu-baseline", action="store_true")

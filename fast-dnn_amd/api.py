@@ -102,6 +102,31 @@ JNI_SYMBOLS = [
 ]
 
 
+def _one_hip_runtime() -> None:
+    """A process must hold ONE HIP runtime.  PyTorch wheels bundle their own ``libamdhip64.so``
+    (same SONAME as ROCm's); if libfast-dnn.so pulls in /opt/rocm's copy first and torch is
+    imported afterwards, torch loads a second runtime, which finds no device.  So when torch is
+    installed but not imported yet, its copy is loaded first and both sides share it (the order
+    bench.py uses anyway: torch first)."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        try:
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib() -> C.CDLL:
     """Load libfast-dnn.so; raises (never falls back) when it has not been built."""
     global _lib
@@ -110,6 +135,7 @@ def lib() -> C.CDLL:
             raise FileNotFoundError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback for the scorer)")
+        _one_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -315,3 +315,50 @@ def test_cli_matches_oracle(tmp_path, mid_model_path, x16):
     txt = np.loadtxt(out_txt, dtype=np.float32)
     assert txt.shape == (100, 1000) and np.abs(txt - want).max() <= 1e-5  # 6 significant digits
     assert subprocess.run([cli, mid_model_path], capture_output=True).returncode != 0
+
+
+def test_quantization_error_against_the_float_net(mid_model_path, x16):
+    """SURVEY 8(f) row 4 -- the reference's accuracy notion (FuncTest.diff, FuncTest.java:59-74):
+    distance of the quantized scorer to the unquantized fp32 net (FeedForwardNetwork.calculate)."""
+    from fast_dnn_amd import convert as CV
+
+    net = F.read_model_bin(mid_model_path)
+    ref = CV.float_forward(net, x16)
+    dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+    q = dnn.calculate(x16)
+    dnn.delete()
+    rep = CV.quantization_report(ref, q)
+    want = CV.quantization_report(ref, Oracle(mid_model_path).calculate(x16))
+    assert rep["nodes_over_0.1"] == want["nodes_over_0.1"]          # same verdict as the CPU reference algorithm
+    assert abs(rep["mean_abs_diff"] - want["mean_abs_diff"]) < 1e-6
+    assert rep["top1_agreement"] > 0.8 and rep["max_abs_diff"] < 0.2, rep
+
+
+def test_device_pointer_lazy_api(mid_model_path, x16):
+    """fdnn_ctx_forward_hidden_device / fdnn_ctx_lazy_output_batch_device: same numbers as the
+    host-pointer calls, buffers owned by the caller (torch only provides the device memory)."""
+    import torch
+
+    masks = F.generate_masks(100, 1000, 0.40, 0.03, seed=11)
+    dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+    ctx = dnn.getNewLazyContext(100)
+    ctx.calculateUntilOutput(x16)
+    want = ctx.calculateForOutputNodesBatch(masks)
+    ctx.delete()
+    s = torch.cuda.Stream()
+    xd = torch.from_numpy(x16).cuda()
+    md = torch.from_numpy(masks).cuda()
+    od = torch.zeros((100, 1000), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctx = dnn.getNewLazyContext(100)
+    ctx.calculateUntilOutputDevice(xd.data_ptr(), s.cuda_stream)
+    ctx.calculateForOutputNodesBatchDevice(md.data_ptr(), od.data_ptr(), 0, 100, s.cuda_stream)
+    ctx.calculateForOutputNodesBatchDevice(md[40:].data_ptr(), od[40:].data_ptr(), 40, 17, s.cuda_stream)  # sub-range again
+    s.synchronize()
+    assert (od.cpu().numpy() == want).all()
+    dense = torch.zeros((100, 1000), dtype=torch.float32, device="cuda")
+    dnn.calculate_device(xd.data_ptr(), 100, dense.data_ptr(), s.cuda_stream)
+    s.synchronize()
+    assert np.abs(dense.cpu().numpy() - dnn.calculate(x16)).max() == 0
+    ctx.delete()
+    dnn.delete()
