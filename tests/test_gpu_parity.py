@@ -334,6 +334,29 @@ def test_quantization_error_against_the_float_net(mid_model_path, x16):
     assert rep["top1_agreement"] > 0.8 and rep["max_abs_diff"] < 0.2, rep
 
 
+def test_shard_of_the_million_frame_config(net_model_path):
+    """BASELINE configs[4]: 1 M frames over 8 GPUs = 125 000 frames per device in one call
+    (4 GB of probabilities).  Spot frames must equal the oracle, every row must sum to one, and
+    the batch must agree with the same frames scored in a small batch (no dependence on n)."""
+    import torch
+
+    n = 125_000
+    base = F.synth_features(1000, 432, seed=31)
+    xd = torch.from_numpy(base).cuda().repeat(n // 1000, 1).contiguous()
+    out = torch.empty((n, 8000), dtype=torch.float32, device="cuda")
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    dnn.calculate_device(xd.data_ptr(), n, out.data_ptr(), 0)
+    torch.cuda.synchronize()
+    sums = out.sum(1)
+    assert float((sums - 1).abs().max()) < 1e-4
+    small = dnn.calculate(base[:8])
+    for rep in (0, 57, 124):  # the 1000-frame block repeats: rows rep*1000 + i equal rows i
+        assert np.abs(out[rep * 1000: rep * 1000 + 8].cpu().numpy() - small).max() == 0
+    want = Oracle(net_model_path).calculate(base[:2])
+    assert np.abs(out[124_000:124_002].cpu().numpy() - want).max() <= TIGHT
+    dnn.delete()
+
+
 def test_device_pointer_lazy_api(mid_model_path, x16):
     """fdnn_ctx_forward_hidden_device / fdnn_ctx_lazy_output_batch_device: same numbers as the
     host-pointer calls, buffers owned by the caller (torch only provides the device memory)."""
