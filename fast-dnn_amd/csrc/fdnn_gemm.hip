@@ -240,26 +240,63 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
   for (int i = 0; i < FDNN_GEMM_PAD; ++i) asm volatile("s_nop 0");
 #endif
 
+  // ROT (double-buffered 8-wave shapes): the step's one barrier sits before its LAST sub-step
+  // instead of before its first.  At that point every wave holds the stage's last fragments in
+  // registers, so the stage buffer is free (refill starts at once and has a whole step to
+  // land) and the next stage, loaded a step ago, is verified; the next step's first fragments
+  // are requested right after the barrier and their LDS latency hides behind the last
+  // sub-step's MFMAs instead of idling the matrix pipe after every barrier
+  // (tools/ubench_tile.hip, k-loop of one layer: 27.7 us classic, 22.9 us rotated).
+  constexpr bool ROT = STAGES == 2 && BK / 32 >= 4;
+  constexpr int SUB = BK / 32;
+  constexpr int ROT_D0 = (NLD + 1) / 2;  // loads issued right after the barrier; the rest before the next sub-step 0
+  v4i a[2][2], b[2][NF];  // MFMA operand fragments, double buffered over the sub-steps
+  auto load_frags = [&](const char *wt_, const char *at_, int kt_, int kk, int set) {
+#if !(FDNN_GEMM_DEBUG & 4)
+    (void)kt_;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) a[set][mi] = read_frag<BK>(wt_, 64 * wm + 32 * mi + frow, kk * 2 + fch);
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni) b[set][ni] = read_frag<BK>(at_, arow0 + 32 * ni + frow, kk * 2 + fch);
+#else
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) a[set][mi] = v4i{kt_, kk, mi, lane};
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni) b[set][ni] = v4i{kt_, kk, ni, lane};
+#endif
+  };
+  if (ROT) {
+    if (KT > 1 && !(FDNN_GEMM_DEBUG & 1)) stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // once: stage 0 (and 1) landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    load_frags(smem, smem + Cfg::W_BYTES, 0, 0, 0);
+  }
+
   int buf = 0;
   for (int kt = 0; kt < KT; ++kt) {
 #if FDNN_GEMM_DEBUG & 64
     if (kt == 1) FDNN_TS(2);
 #endif
-    // stage kt has landed once at most (STAGES-2) younger stages are outstanding
-    if (STAGES > 2 && kt + STAGES - 2 < KT) {
-      if (STAGES == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::MIN_LOADS) : "memory");
-      if (STAGES == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Cfg::MIN_LOADS) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!ROT) {
+      // stage kt has landed once at most (STAGES-2) younger stages are outstanding
+      if (STAGES > 2 && kt + STAGES - 2 < KT) {
+        if (STAGES == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::MIN_LOADS) : "memory");
+        if (STAGES == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Cfg::MIN_LOADS) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // everyone's share of stage kt landed; everyone is done reading stage kt-1
+      asm volatile("" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();  // everyone's share of stage kt landed; everyone is done reading stage kt-1
-    asm volatile("" ::: "memory");
-    // The refill of the buffer freed by the barrier is NOT issued here in one burst: a wave
+    // The refill of the buffer freed by the barrier is NOT issued in one burst: a wave
     // issues in order, and NLD back-to-back LDS-DMA loads queue behind the other seven
     // waves' loads in the CU's one address path, which keeps the wave's MFMAs waiting
     // (tools/ubench_pipe.hip: 4550 vs 3400 cycles per 128-k step).  The loads are spread
     // over the k sub-steps instead, each group issued just before a block of MFMAs.
-    const bool refill = kt + STAGES - 1 < KT && !(FDNN_GEMM_DEBUG & 1);
+    // (ROT: stage kt+1 goes into the buffer freed at the previous barrier; its first ROT_D0
+    // loads went out right after that barrier.)
+    const bool refill = (ROT ? (kt >= 1 && kt + 1 < KT) : (kt + STAGES - 1 < KT)) && !(FDNN_GEMM_DEBUG & 1);
     int nb = buf + STAGES - 1;
     if (nb >= STAGES) nb -= STAGES;
 #ifdef FDNN_GEMM_BURST
@@ -324,41 +361,47 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #endif
     // Fragments are double buffered in registers: the ds_read_b128s of sub-step
     // kk+1 are in flight while the 2*NF MFMAs of sub-step kk issue, so a wave's
-    // matrix pipe only waits for LDS once per k-step (the first sub-step).
-    v4i a[2][2], b[2][NF];
-    auto load_frags = [&](int kk, int set) {
-#if !(FDNN_GEMM_DEBUG & 4)
+    // matrix pipe only waits for LDS once per k-step (the first sub-step; never with ROT).
+    if (!ROT) load_frags(wt, at, kt, 0, 0);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[set][mi] = read_frag<BK>(wt, 64 * wm + 32 * mi + frow, kk * 2 + fch);
-#pragma unroll
-      for (int ni = 0; ni < NF; ++ni) b[set][ni] = read_frag<BK>(at, arow0 + 32 * ni + frow, kk * 2 + fch);
-#else
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) a[set][mi] = v4i{kt, kk, mi, lane};
-#pragma unroll
-      for (int ni = 0; ni < NF; ++ni) b[set][ni] = v4i{kt, kk, ni, lane};
-#endif
-    };
-    load_frags(0, 0);
-#pragma unroll
-    for (int kk = 0; kk < BK / 32; ++kk) {
-      if (kk + 1 < BK / 32) load_frags(kk + 1, (kk + 1) & 1);
+    for (int kk = 0; kk < SUB; ++kk) {
+      if (kk + 1 < SUB) load_frags(wt, at, kt, kk + 1, (kk + 1) & 1);
 #ifndef FDNN_GEMM_BURST
-      if (refill) {
-        constexpr int SUB = BK / 32;
+      if (ROT) {
+        if (refill && kk == 0) {  // the second half of stage kt+1's loads (the first went out after the barrier)
+#pragma unroll
+          for (int i = ROT_D0; i < NLD; ++i) stage_load(kt + 1, nb, i);
+        }
+        if (kk == SUB - 1) {
+          // all of this stage's fragments are in registers or in flight: drain my LDS reads and
+          // my share of stage kt+1, meet the other waves, then start the next step's first reads
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (kt + 1 < KT) {
+            const char *wn_ = smem + nb * Cfg::STAGE;
+            load_frags(wn_, wn_ + Cfg::W_BYTES, kt + 1, 0, 0);
+          }
+          if (kt + 2 < KT && !(FDNN_GEMM_DEBUG & 1)) {  // stage kt+2 into the buffer this step just released
+#pragma unroll
+            for (int i = 0; i < ROT_D0; ++i) stage_load(kt + 2, buf, i);
+          }
+        }
+      } else if (refill) {
+        // classic ring: spread over the sub-steps (tools/ubench_tile.hip, k-loop of a layer:
+        // 3/2/2/2 27.7 us, 9/0/0/0 28.8, 5/4/0/0 26.8)
+        constexpr int SPAN = (STAGES == 2 && SUB >= 4) ? SUB / 2 : SUB;
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-          if (i * SUB / NLD == kk) stage_load(kt + STAGES - 1, nb, i);
+          if (i * SPAN / NLD == kk) stage_load(kt + STAGES - 1, nb, i);
       }
 #endif
 #if !(FDNN_GEMM_DEBUG & 2)
-      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
           acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kk & 1][mi], b[kk & 1][ni], acc[mi][ni], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
 #else
 #pragma unroll
       for (int ni = 0; ni < NF; ++ni)
