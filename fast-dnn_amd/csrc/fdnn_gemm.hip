@@ -266,11 +266,14 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #endif
   };
   if (ROT) {
-    if (KT > 1 && !(FDNN_GEMM_DEBUG & 1)) stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // once: stage 0 (and 1) landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // once: stage 0 landed
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     load_frags(smem, smem + Cfg::W_BYTES, 0, 0, 0);
+    if (KT > 1 && !(FDNN_GEMM_DEBUG & 1)) {  // stage 1 is step 0's refill: first half now, the rest before sub-step 0's MFMAs
+#pragma unroll
+      for (int i = 0; i < ROT_D0; ++i) stage_load(1, 1, i);
+    }
   }
 
   int buf = 0;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     // over the k sub-steps instead, each group issued just before a block of MFMAs.
     // (ROT: stage kt+1 goes into the buffer freed at the previous barrier; its first ROT_D0
     // loads went out right after that barrier.)
-    const bool refill = (ROT ? (kt >= 1 && kt + 1 < KT) : (kt + STAGES - 1 < KT)) && !(FDNN_GEMM_DEBUG & 1);
+    const bool refill = kt + STAGES - 1 < KT && !(FDNN_GEMM_DEBUG & 1);
     int nb = buf + STAGES - 1;
     if (nb >= STAGES) nb -= STAGES;
 #ifdef FDNN_GEMM_BURST

@@ -207,6 +207,12 @@ int main() {
   run<4, 2, 1440, 6>("8 waves, ROTATED, 1/4/4/0, no setprio", w, a, out);
   run<4, 2, 450, 6>("8 waves, ROTATED, 0/4/5/0, no setprio", w, a, out);
   run<4, 2, 5400, 2>("8 waves, classic, 5/4/0/0, no setprio", w, a, out);
+  run<4, 2, 6300, 6>("8 waves, ROTATED, 6/3/0/0, no setprio", w, a, out);
+  run<4, 2, 7200, 6>("8 waves, ROTATED, 7/2/0/0, no setprio", w, a, out);
+  run<4, 2, 9000, 6>("8 waves, ROTATED, 9/0/0/0, no setprio", w, a, out);
+  run<4, 2, 3600, 6>("8 waves, ROTATED, 3/6/0/0, no setprio", w, a, out);
+  run<4, 2, 5220, 6>("8 waves, ROTATED, 5/2/2/0, no setprio", w, a, out);
+  run<4, 2, 5400, 7>("8 waves, ROTATED, 5/4/0/0, no setprio, NO barrier", w, a, out);
   run<2, 4, 5544, 0>("4 waves, wave tile 128x160", w, a, out);
   return 0;
 }
