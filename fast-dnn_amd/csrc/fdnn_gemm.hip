@@ -34,6 +34,7 @@
 #include "fdnn_kernels.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 // Timing experiments only (never set in the shipped build): bit 0 = no staging
 // loads after the prologue, bit 1 = no MFMA, bit 2 = no LDS fragment reads.
@@ -86,7 +87,9 @@ __device__ __forceinline__ v4i read_frag(const char *tile, int row, int chunk) {
 
 // FAST: the layer's 3-op division was validated against IEEE division at load
 // (every layer of a sane net); !FAST keeps the true divide for the rest.
-template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool TAP, bool FAST>
+// PLAIN (output layer only): no mask, no taps, output width a multiple of 4 -- the dense
+// production call, without the per-group branches of the general epilogue.
+template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool TAP, bool FAST, bool PLAIN = false>
 __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (buffer-resource builtins are device-only)
   using Cfg = GemmCfg<NF, WN, BK, STAGES>;
@@ -453,56 +456,66 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     // Each wave parks one 64-node x 32-frame block of e in its own LDS tile and writes
     // it out as 256-byte row segments (a direct float4 store per accumulator group
     // would touch 32 rows x 32 bytes per instruction and is address-processing bound).
+    //
+    // PLAIN (a separate kernel instance: no mask, no taps, output width a multiple of 4 = the
+    // dense production call) carries none of the per-group branches of the general code --
+    // those branches, not the 318 MB of stores, were 25-50 k cycles of a 95 k-cycle tile.
     constexpr int kOS = 64 + 4;  // floats per tile row
     float *wtile = reinterpret_cast<float *>(smem + 8192) + wave * (32 * kOS);
     const int ncol0 = m0 + 64 * wm;
+    {
 #pragma unroll
-    for (int ni = 0; ni < NF; ++ni) {
-      const int f = fw0 + 32 * ni + frow;
-      const bool live = f < p.n;
+      for (int ni = 0; ni < NF; ++ni) {
+        const int f = fw0 + 32 * ni + frow;
+        const bool live = f < p.n;
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nb = ncol0 + 32 * mi + 8 * g + 4 * half;  // 4 consecutive nodes nb..nb+3
-          const float4 b4 = *reinterpret_cast<const float4 *>(bias_s + (nb - m0));
-          const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
-          uint32_t mbits = 0x01010101u;
-          if (p.mask && live && nb < p.rows) {
-            const int8_t *mp = p.mask + static_cast<size_t>(f) * p.rows + nb;
-            if (vec4) {
-              mbits = *reinterpret_cast<const uint32_t *>(mp);
-            } else {
-              mbits = 0;
-              for (int q = 0; q < 4; ++q)
-                if (nb + q < p.rows && mp[q]) mbits |= 0xffu << (8 * q);
+          for (int g = 0; g < 4; ++g) {
+            const int nb = ncol0 + 32 * mi + 8 * g + 4 * half;  // 4 consecutive nodes nb..nb+3
+            const float4 b4 = *reinterpret_cast<const float4 *>(bias_s + (nb - m0));
+            const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
+            uint32_t mbits = 0x01010101u;
+            if (!PLAIN && p.mask && live && nb < p.rows) {
+              const int8_t *mp = p.mask + static_cast<size_t>(f) * p.rows + nb;
+              if (vec4) {
+                mbits = *reinterpret_cast<const uint32_t *>(mp);
+              } else {
+                mbits = 0;
+                for (int q = 0; q < 4; ++q)
+                  if (nb + q < p.rows && mp[q]) mbits |= 0xffu << (8 * q);
+              }
             }
-          }
-          float e[4];
+            // PLAIN: the whole group of 4 nodes is inside or outside the layer (rows % 4 == 0)
+            const bool in4 = nb < p.rows;
+            float e[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int av = acc[mi][ni][g * 4 + q];
-            if (TAP && live && nb + q < p.rows) p.tap_acc[static_cast<size_t>(f) * p.rows + nb + q] = av;
-            float z = dequant<FAST>(av, p.coef, p.rcp_coef) + bj[q];  // sum/coef, then += bias (dnn.cc:311, :446)
-            if (((mbits >> (8 * q)) & 0xffu) == 0) z = 0.0f;
-            if (TAP && live && nb + q < p.rows) p.tap_logit[static_cast<size_t>(f) * p.rows + nb + q] = z;
-            e[q] = (nb + q < p.rows) ? __expf(z) : 0.0f;
-            psum[ni] += e[q];
+            for (int q = 0; q < 4; ++q) {
+              const int av = acc[mi][ni][g * 4 + q];
+              if (!PLAIN && TAP && live && nb + q < p.rows) p.tap_acc[static_cast<size_t>(f) * p.rows + nb + q] = av;
+              float z = dequant<FAST>(av, p.coef, p.rcp_coef) + bj[q];  // sum/coef, then += bias (dnn.cc:311, :446)
+              if (!PLAIN && ((mbits >> (8 * q)) & 0xffu) == 0) z = 0.0f;
+              if (!PLAIN && TAP && live && nb + q < p.rows) p.tap_logit[static_cast<size_t>(f) * p.rows + nb + q] = z;
+              e[q] = (PLAIN ? in4 : (nb + q < p.rows)) ? __expf(z) : 0.0f;
+              psum[ni] += e[q];
+            }
+            *reinterpret_cast<float4 *>(wtile + frow * kOS + (nb - ncol0)) = make_float4(e[0], e[1], e[2], e[3]);
           }
-          *reinterpret_cast<float4 *>(wtile + frow * kOS + (nb - ncol0)) = make_float4(e[0], e[1], e[2], e[3]);
         }
-      }
-      // wave-private tile: 8 x (4 rows x 256 B) stores
+        // wave-private tile: 8 x (4 rows x 256 B) stores
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        const int row = r * 4 + (lane >> 4), col = (lane & 15) * 4;
-        const float4 v = *reinterpret_cast<const float4 *>(wtile + row * kOS + col);
-        const int ff = fw0 + 32 * ni + row;
-        if (ff < p.n) {
+        for (int r = 0; r < 8; ++r) {
+          const int row = r * 4 + (lane >> 4), col = (lane & 15) * 4;
+          const float4 v = *reinterpret_cast<const float4 *>(wtile + row * kOS + col);
+          const int ff = fw0 + 32 * ni + row;
           float *op = p.out + static_cast<size_t>(ff) * p.rows + ncol0 + col;
-          if (vec4) {
-            if (ncol0 + col < p.rows) *reinterpret_cast<float4 *>(op) = v;
-          } else {
+          if (PLAIN || vec4) {
+#if FDNN_GEMM_DEBUG & 16  // ablation: no output stores
+            if (v.x == 1234.5f && ff < p.n && ncol0 + col < p.rows) *reinterpret_cast<float4 *>(op) = v;
+#else
+            if (ff < p.n && ncol0 + col < p.rows) *reinterpret_cast<float4 *>(op) = v;
+#endif
+          } else if (ff < p.n) {
             const float vv[4] = {v.x, v.y, v.z, v.w};
             for (int q = 0; q < 4; ++q)
               if (ncol0 + col + q < p.rows) op[q] = vv[q];
@@ -586,11 +599,11 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #if FDNN_GEMM_DEBUG & 128
   if (!OUTPUT && tid == 0) printf("B %d %llu %llu\n", blockIdx.x, rt0, rt1);
 #else
-  if (!OUTPUT && tid == 0 && (blockIdx.x % 37) == 0)
+  if (tid == 0 && (blockIdx.x % (OUTPUT ? 149 : 37)) == 0)
 #endif
 #if !(FDNN_GEMM_DEBUG & 128)
-    printf("blk %4d  rt %llu (+%llu) | prologue %6lld  first-stage %6lld  mainloop %7lld (fix %d: %lld)  lut %6lld  epilogue %7lld  total %7lld cyc\n",
-           blockIdx.x, rt0, rt1 - rt0, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], n_fix_done, ts_fix, ts[4] - ts[3], ts[5] - ts[4],
+    printf("%s %4d  rt %llu (+%llu) | prologue %6lld  first-stage %6lld  mainloop %7lld (fix %d: %lld)  lut %6lld  epilogue %7lld  total %7lld cyc\n",
+           OUTPUT ? "OUT" : "blk", blockIdx.x, rt0, rt1 - rt0, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], n_fix_done, ts_fix, ts[4] - ts[3], ts[5] - ts[4],
            ts[5] - ts[0]);
 #endif
 #endif
@@ -604,14 +617,18 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
   const int blocks = 8 * MT * ((NT + 7) / 8);
   auto k_prod = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST>;
   auto k_tap = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, true, FAST>;
+  auto k_plain = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT>;  // hidden layers: same as k_prod
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_prod), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_tap), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set = true;
   }
   if (p.tap_acc)
     hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+  else if (OUTPUT && p.mask == nullptr && (p.rows & 3) == 0)
+    hipLaunchKernelGGL(k_plain, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else
     hipLaunchKernelGGL(k_prod, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
 }
