@@ -150,6 +150,20 @@ def main() -> None:
     torch.cuda.synchronize()
     prof = dnn.profileEnd()
 
+    # third pass (rank 0, N=1 only, informational): the other layer-0 flavour on the same batch
+    alt = None
+    if world == 1:
+        dnn.setInputLayerFma(not args.l0_fma)
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        alt = n * args.steps / (time.perf_counter() - t1)
+        dnn.setInputLayerFma(args.l0_fma)
+
     if rank == 0:
         # HBM-side bytes per launch of the dominant kernel come from the committed PMC passes
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as the
@@ -196,6 +210,9 @@ def main() -> None:
                 "avg_launch_ms": round(hid_ms, 4), "launches": hid["launches"],
             },
             "kernel_ms_per_step": kernels_ms,
+            "other_layer0_flavour": None if alt is None else {
+                "layer0_numerics": "unfused (canonical)" if args.l0_fma else "fused (reference built -march=native), fp32 MFMA",
+                "frames_per_s": round(alt, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model_path)

@@ -46,7 +46,6 @@ namespace fdnn {
 namespace {
 
 constexpr int G_BM = 256;
-constexpr int kFixCap = 64;  // saturation-fix entries per 64-node group kept in LDS (the rest: global, slow)
 
 template <int NF, int WN, int BK, int STAGES>
 struct GemmCfg {
@@ -61,13 +60,12 @@ struct GemmCfg {
   static constexpr int W_SLABS = G_BM / RPI;
   static constexpr int A_SLABS = FT / RPI;
   static constexpr int MIN_LOADS = W_SLABS / NW + A_SLABS / NW;  // fewest loads any wave issues per stage
-  // Behind the ring: 4 node groups x kFixCap saturation-fix entries, then the sigmoid table
-  // (3 KiB window) and this tile's 256 biases, both LDS-DMA'd before the first stage so the
-  // epilogue starts without a load phase.  After the k-loop the ring is reused for the s8
+  // Behind the ring: the sigmoid table (3 KiB window) and this tile's 256 biases, both
+  // LDS-DMA'd before the first stage so the epilogue starts without a load phase.  After the k-loop the ring is reused for the s8
   // output tile FT x (256+16) bytes (hidden layers) / the per-wave e tiles (output layer).
   static constexpr int EPI = 8192 + FT * (G_BM + 16);
   static constexpr int FIX_OFF = STAGE * STAGES;
-  static constexpr int AUX_OFF = FIX_OFF + 4 * kFixCap * 8;  // table at +0, biases at +3072
+  static constexpr int AUX_OFF = FIX_OFF;  // table at +0, biases at +3072
   static constexpr int RING = AUX_OFF + 4096;
   static constexpr int LDS = RING > EPI ? RING : EPI;
   static_assert(EPI <= FIX_OFF, "the epilogue tile must not reach the table/biases");
@@ -212,24 +210,22 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
   // added to the accumulator that holds (node, frame).  The entry walk and the register
   // select are wave-uniform; a layer without risky pairs has fix_k_next = INT_MAX.
   //
-  // The group's first kFixCap entries are copied into LDS before the k-loop: a global
-  // load issued inside the loop returns in order BEHIND the stage's LDS-DMA loads,
-  // i.e. every entry fetched from memory would cost a whole stage latency.
-  const FixEntry *ent = reinterpret_cast<const FixEntry *>(p.fix_ent);
-  FixEntry *fix_s = reinterpret_cast<FixEntry *>(smem + Cfg::STAGE * STAGES) + wm * kFixCap;
-  int fix_e = 0, fix_e0 = 0, fix_end = 0, fix_k_next = INT_MAX;
-  FixEntry fix_cur{0, 0, 0, 0};
-  if (ent) {
+  int fix_e = 0, fix_end = 0, fix_k_next = INT_MAX;
+  // Entries are walked with SCALAR loads (constant address space: s_load_dwordx2 into SGPRs, two
+  // entries ahead): no LDS round trip and no v_readfirstlane per entry, and the scalar cache
+  // path does not queue behind the LDS-DMA loads as a vector load issued in the loop would
+  // (-4.5 % on a Gaussian-weight layer against an LDS copy of the list).
+  typedef const __attribute__((address_space(4))) uint64_t *FixPtr;
+  const FixPtr ent_c = (FixPtr)(uintptr_t)p.fix_ent;
+  uint64_t fix_raw = 0, fix_raw_nxt = 0;  // {u16 k, s8 w0, s8 w1, s32 node}
+  if (p.fix_ent) {
     const int grp = (m0 >> 6) + wm;
-    fix_e0 = fix_e = p.fix_grp[grp];
-    fix_end = p.fix_grp[grp + 1];
+    fix_e = __builtin_amdgcn_readfirstlane(p.fix_grp[grp]);
+    fix_end = __builtin_amdgcn_readfirstlane(p.fix_grp[grp + 1]);
     if (fix_e < fix_end) {
-      fix_cur = ent[fix_e];
-      fix_k_next = fix_cur.k;
-      if (wn == 0) {
-        for (int i = lane; i < min(fix_end - fix_e0, kFixCap); i += 64) fix_s[i] = ent[fix_e0 + i];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // written before the k-loop's first (raw) barrier
-      }
+      fix_raw = ent_c[fix_e];
+      if (fix_e + 1 < fix_end) fix_raw_nxt = ent_c[fix_e + 1];
+      fix_k_next = static_cast<int>(fix_raw & 0xffff);
     }
   }
   FDNN_TS(1);
@@ -315,10 +311,9 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     const int fe0 = fix_e;
 #endif
     while (fix_k_next < (kt + 1) * BK) {  // rare: a risky pair lives in this k-step
-      const FixEntry t = fix_cur;  // fetched when the previous entry was consumed
-      const int node = __builtin_amdgcn_readfirstlane(t.node) - (m0 + 64 * wm);  // 0..63
-      const int kl = __builtin_amdgcn_readfirstlane(t.k) - kt * BK;              // even, 0..BK-2
-      const int w0 = __builtin_amdgcn_readfirstlane(t.w0), w1 = __builtin_amdgcn_readfirstlane(t.w1);
+      const int node = static_cast<int>(fix_raw >> 32) - (m0 + 64 * wm);  // 0..63
+      const int kl = static_cast<int>(fix_raw & 0xffff) - kt * BK;          // even, 0..BK-2
+      const int w0 = static_cast<int8_t>(fix_raw >> 16), w1 = static_cast<int8_t>(fix_raw >> 24);
       const int rr = node & 31;
       const int idx = (node >> 5) * 16 + (rr & 3) + 4 * (rr >> 3);  // mi*16 + reg
       const bool mine = (lane >> 5) == ((rr >> 2) & 1);
@@ -352,12 +347,9 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
         }
       }
       ++fix_e;
-      if (fix_e < fix_end) {
-        fix_cur = (fix_e - fix_e0 < kFixCap) ? fix_s[fix_e - fix_e0] : ent[fix_e];  // LDS copy; global only past the cap
-        fix_k_next = __builtin_amdgcn_readfirstlane(fix_cur.k);
-      } else {
-        fix_k_next = INT_MAX;
-      }
+      fix_raw = fix_raw_nxt;
+      fix_k_next = fix_e < fix_end ? static_cast<int>(fix_raw & 0xffff) : INT_MAX;
+      if (fix_e + 1 < fix_end) fix_raw_nxt = ent_c[fix_e + 1];
     }
 #if FDNN_GEMM_DEBUG & 64
     if (fix_e != fe0) {
