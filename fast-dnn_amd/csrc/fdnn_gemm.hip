@@ -301,9 +301,6 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     const bool refill = kt + STAGES - 1 < KT && !(FDNN_GEMM_DEBUG & 1);
     int nb = buf + STAGES - 1;
     if (nb >= STAGES) nb -= STAGES;
-#ifdef FDNN_GEMM_BURST
-    if (refill) stage(kt + STAGES - 1, nb);
-#endif
     const char *wt = smem + buf * Cfg::STAGE;
     const char *at = wt + Cfg::W_BYTES;
 #if FDNN_GEMM_DEBUG & 64
@@ -364,7 +361,6 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #pragma unroll
     for (int kk = 0; kk < SUB; ++kk) {
       if (kk + 1 < SUB) load_frags(wt, at, kt, kk + 1, (kk + 1) & 1);
-#ifndef FDNN_GEMM_BURST
       if (ROT) {
         if (refill && kk == 0) {  // the second half of stage kt+1's loads (the first went out after the barrier)
 #pragma unroll
@@ -386,14 +382,11 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
           }
         }
       } else if (refill) {
-        // classic ring: spread over the sub-steps (tools/ubench_tile.hip, k-loop of a layer:
-        // 3/2/2/2 27.7 us, 9/0/0/0 28.8, 5/4/0/0 26.8)
-        constexpr int SPAN = (STAGES == 2 && SUB >= 4) ? SUB / 2 : SUB;
+        // classic 3-stage ring (4-wave shapes): spread over the sub-steps
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-          if (i * SPAN / NLD == kk) stage_load(kt + STAGES - 1, nb, i);
+          if (i * SUB / NLD == kk) stage_load(kt + STAGES - 1, nb, i);
       }
-#endif
 #if !(FDNN_GEMM_DEBUG & 2)
 #pragma unroll
       for (int ni = 0; ni < NF; ++ni)
