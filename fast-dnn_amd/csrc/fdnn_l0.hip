@@ -117,23 +117,41 @@ __global__ __launch_bounds__(256, TI <= 4 ? 4 : 2) void l0_valu_kernel(L0Params 
       for (int i = 0; i < TI; ++i) xv[i] = *reinterpret_cast<const float4 *>(xb + (ty * TI + i) * LD + k4 * 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) wv[j] = *reinterpret_cast<const float4 *>(wb + (tx + 16 * j) * LD + k4 * 4);
+      if (!FMA) {
+        // InputActivations, canonical flavour: four lane partial sums over k mod 4, multiply and
+        // add rounded separately (dnn.cc:233-238).  Packed fp32 by hand: chains (0,1) and (2,3)
+        // sit in even-aligned register pairs, as do the halves of the ds_read_b128 operands ->
+        // v_pk_mul_f32 + v_pk_add_f32 without a single shuffle; the eight products of a frame
+        // first, so that no add waits on the multiply right before it (0.403 -> 0.391 ms; the
+        // SLP vectorizer's own packing of the scalar code is slower: keep -fno-slp-vectorize)
+        typedef float v2f __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+          const v2f x01 = {xv[i].x, xv[i].y}, x23 = {xv[i].z, xv[i].w};
+          v2f pr[4][2];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            pr[j][0] = x01 * v2f{wv[j].x, wv[j].y};
+            pr[j][1] = x23 * v2f{wv[j].z, wv[j].w};
+          }
+          asm volatile("" : "+v"(pr[0][0]), "+v"(pr[0][1]), "+v"(pr[1][0]), "+v"(pr[1][1]), "+v"(pr[2][0]), "+v"(pr[2][1]),
+                       "+v"(pr[3][0]), "+v"(pr[3][1]));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const v2f a01 = v2f{acc[i][j][0], acc[i][j][1]} + pr[j][0], a23 = v2f{acc[i][j][2], acc[i][j][3]} + pr[j][1];
+            acc[i][j][0] = a01.x; acc[i][j][1] = a01.y; acc[i][j][2] = a23.x; acc[i][j][3] = a23.y;
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          // InputActivations: four lane partial sums over k mod 4 (dnn.cc:233-238)
-          if (FMA) {
-            acc[i][j][0] = fmaf(xv[i].x, wv[j].x, acc[i][j][0]);
-            acc[i][j][1] = fmaf(xv[i].y, wv[j].y, acc[i][j][1]);
-            acc[i][j][2] = fmaf(xv[i].z, wv[j].z, acc[i][j][2]);
-            acc[i][j][3] = fmaf(xv[i].w, wv[j].w, acc[i][j][3]);
-          } else {
-            // (grouping the four multiplies before the four adds changes nothing: 0.427 vs 0.430 ms)
-            acc[i][j][0] = acc[i][j][0] + xv[i].x * wv[j].x;
-            acc[i][j][1] = acc[i][j][1] + xv[i].y * wv[j].y;
-            acc[i][j][2] = acc[i][j][2] + xv[i].z * wv[j].z;
-            acc[i][j][3] = acc[i][j][3] + xv[i].w * wv[j].w;
-          }
+        for (int j = 0; j < 4; ++j) {  // fused flavour on the VALU (FDNN_L0_FMA_VALU=1; production uses l0_mfma_kernel)
+          acc[i][j][0] = fmaf(xv[i].x, wv[j].x, acc[i][j][0]);
+          acc[i][j][1] = fmaf(xv[i].y, wv[j].y, acc[i][j][1]);
+          acc[i][j][2] = fmaf(xv[i].z, wv[j].z, acc[i][j][2]);
+          acc[i][j][3] = fmaf(xv[i].w, wv[j].w, acc[i][j][3]);
         }
     }
     if (c + 1 < nchunk) lstore(buf ^ 1);
