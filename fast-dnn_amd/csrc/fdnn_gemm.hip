@@ -17,9 +17,11 @@
 // nodes [64wm, 64wm+64) x frames [32*NF*wn, +32*NF) = 2 x NF MFMA 32x32 tiles
 // (32*NF accumulator registers).
 //
-// L2 -> LDS: global_load_lds_dwordx4 (LDS-DMA, 1 KiB per wave instruction) into a
-// ring of STAGES buffers, one raw barrier per k-step, loads kept in flight across
-// it with a counted s_waitcnt vmcnt.  The k-step is BK bytes of every row; with
+// L2 -> LDS: buffer_load_dwordx4 ... lds (LDS-DMA, 1 KiB per wave instruction) into a
+// ring of STAGES buffers, one raw barrier per k-step.  The 8-wave double-buffered shapes
+// put that barrier before the step's LAST 32-deep sub-step ("rotated", see ROT below);
+// the 4-wave 3-stage shapes keep it at the top with loads in flight across it under a
+// counted s_waitcnt vmcnt.  The k-step is BK bytes of every row; with
 // BK = 128 each row segment is one whole 128-byte cache line, which the vector
 // L1 serves at twice the rate of 64-byte segments (tools/ubench_glds.hip:
 // 29 vs 17 TB/s chip-wide from L2).

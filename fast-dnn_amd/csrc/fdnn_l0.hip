@@ -10,11 +10,13 @@
 //
 //   l0_valu_kernel  canonical numerics (reference built -O2 -msse4 -ffp-contract=off):
 //                   multiply and add are separate roundings -> VALU v_pk_mul_f32 +
-//                   v_pk_add_f32, two lane-ops per MAC; bound by the fp32 vector rate.
+//                   v_pk_add_f32 (packed by hand), two lane-ops per MAC; bound by the
+//                   fp32 vector instruction rate (83 % of what a bare mul/add loop reaches).
 //   l0_mfma_kernel  the reference as its own Makefile builds it on an FMA host
 //                   (-march=native contracts mul+add): each chain is an fmaf chain,
-//                   which is bit-for-bit what v_mfma_f32_32x32x2_f32 computes, so the
-//                   four chains become four accumulator tiles fed k = c, c+4, c+8, ...
+//                   which is bit-for-bit what one block of v_mfma_f32_32x32x1_2b_f32
+//                   computes, so the four chains become four accumulator blocks fed
+//                   k = c, c+4, c+8, ...  (validated bit-for-bit against the FMA build).
 #include "fdnn_device.hpp"
 #include "fdnn_kernels.hpp"
 
