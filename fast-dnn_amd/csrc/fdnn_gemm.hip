@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     if (!ROT) {
       // stage kt has landed once at most (STAGES-2) younger stages are outstanding
       if (STAGES > 2 && kt + STAGES - 2 < KT) {
-        if (STAGES == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(Cfg::MIN_LOADS) : "memory");
-        if (STAGES == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * Cfg::MIN_LOADS) : "memory");
+        static_assert((STAGES - 2) * Cfg::MIN_LOADS <= 63, "vmcnt is a 6-bit counter");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * Cfg::MIN_LOADS) : "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -627,8 +627,15 @@ void launch_qgemm(const QGemmParams &p, hipStream_t s) {
     return;
   }
   switch (p.frame_tile) {
-    // 4 waves, 64-byte k-step, 3-stage ring, two workgroups per CU
-    case 128: launch_cfg<4, 1, 64, 3, OUTPUT>(p, s); break;
+    // 4 waves, 64-byte k-step, 3-stage ring, two workgroups per CU; when every workgroup has
+    // a CU of its own anyway (small batches: one latency-bound k-loop per launch) a 6-stage
+    // ring hides twice the load latency per step
+    case 128:
+      if (static_cast<long>(p.rows_pad / G_BM) * (p.n_pad / 128) <= 256 && !p.tap_acc)
+        launch_cfg<4, 1, 64, 6, OUTPUT>(p, s);
+      else
+        launch_cfg<4, 1, 64, 3, OUTPUT>(p, s);
+      break;
     case 160: launch_cfg<5, 1, 64, 3, OUTPUT>(p, s); break;
     // 8 waves, 128-byte k-step (whole cache lines), double buffer, one workgroup per CU
     case 256: launch_cfg<4, 2, 128, 2, OUTPUT>(p, s); break;
