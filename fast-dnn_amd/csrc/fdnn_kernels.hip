@@ -11,8 +11,10 @@ namespace {
 // ---------------------------------------------------------------- soft-max normalisation
 // SoftMax::apply second loop (dnn.cc:541-543): p_i = e_i / total.  total is the
 // sum of the output kernel's per-64-node partials in a fixed order.
-__global__ __launch_bounds__(256) void normalize_kernel(float *out, const float *partial, int n, int partial_ld, int rows,
-                                                        int n_partial) {
+// dst == out scales in place; the per-frame lazy call passes a host-mapped dst instead, so the
+// probabilities land in the caller's pinned buffer without a copy command.
+__global__ __launch_bounds__(256) void normalize_kernel(const float *out, float *dst, const float *partial, int n, int partial_ld,
+                                                        int rows, int n_partial) {
   __shared__ float red[4];
   const int f = blockIdx.x;
   const int tid = threadIdx.x;
@@ -23,19 +25,21 @@ __global__ __launch_bounds__(256) void normalize_kernel(float *out, const float 
   if ((tid & 63) == 0) red[tid >> 6] = s;
   __syncthreads();
   const float total = (red[0] + red[1]) + (red[2] + red[3]);
-  float *row = out + static_cast<size_t>(f) * rows;
+  const float *row = out + static_cast<size_t>(f) * rows;
+  float *drow = dst + static_cast<size_t>(f) * rows;
   if ((rows & 3) == 0) {
-    float4 *r4 = reinterpret_cast<float4 *>(row);
+    const float4 *r4 = reinterpret_cast<const float4 *>(row);
+    float4 *d4 = reinterpret_cast<float4 *>(drow);
     for (int i = tid; i < rows / 4; i += 256) {
       float4 v = r4[i];
       v.x = v.x / total;
       v.y = v.y / total;
       v.z = v.z / total;
       v.w = v.w / total;
-      r4[i] = v;
+      d4[i] = v;
     }
   } else {
-    for (int i = tid; i < rows; i += 256) row[i] = row[i] / total;
+    for (int i = tid; i < rows; i += 256) drow[i] = row[i] / total;
   }
 }
 
@@ -58,9 +62,9 @@ __global__ __launch_bounds__(256) void xor80_kernel(const int8_t *in, uint8_t *o
 
 }  // namespace
 
-void launch_normalize(float *out, const float *partial, int n, int partial_ld, int rows, int n_partial, hipStream_t s) {
+void launch_normalize(float *out, float *dst, const float *partial, int n, int partial_ld, int rows, int n_partial, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(normalize_kernel, dim3(n), dim3(256), 0, s, out, partial, n, partial_ld, rows, n_partial);
+  hipLaunchKernelGGL(normalize_kernel, dim3(n), dim3(256), 0, s, out, dst, partial, n, partial_ld, rows, n_partial);
 }
 
 void launch_fastdiv_check(float coef, float rcp, unsigned long long *d_mismatch, hipStream_t s) {

@@ -63,8 +63,8 @@ struct QGemmParams {
 void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s);
 void launch_qgemm_output(const QGemmParams &p, hipStream_t s);
 
-// out[f][:] /= sum_t partial[t][f]
-void launch_normalize(float *out, const float *partial, int n, int partial_ld, int rows, int n_partial, hipStream_t s);
+// dst[f][:] = out[f][:] / sum_t partial[t][f]   (dst == out: in place; dst may be host-mapped)
+void launch_normalize(float *out, float *dst, const float *partial, int n, int partial_ld, int rows, int n_partial, hipStream_t s);
 
 // Exhaustive check of the 3-op division against IEEE division for every int32
 // accumulator in [-2^26, 2^26]; *d_mismatch receives the count.

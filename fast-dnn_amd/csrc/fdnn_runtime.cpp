@@ -72,7 +72,13 @@ struct fdnn_ctx {
   int8_t *d_mask = nullptr;       // [n][O]
   int last = -1;                  // d_act index holding the last hidden layer, -1 = not computed
   bool pooled = false;
+  // per-frame lazy calls (the JNI contract): host-mapped pinned staging for kPinFrames masks and
+  // result rows -- the output kernel reads the mask and the scale kernel writes the probabilities
+  // straight through these, so a call is two launches and one stream sync, no copy commands
+  int8_t *h_mask_pin = nullptr, *d_mask_pin = nullptr;
+  float *h_out_pin = nullptr, *d_out_pin = nullptr;
 };
+constexpr int kPinFrames = 8;
 
 namespace {
 
@@ -139,6 +145,8 @@ void destroy_ctx(fdnn_ctx *c) {
   hipFree(c->d_out);
   hipFree(c->d_partial);
   hipFree(c->d_mask);
+  if (c->h_mask_pin) hipHostFree(c->h_mask_pin);
+  if (c->h_out_pin) hipHostFree(c->h_out_pin);
   if (c->done) hipEventDestroy(c->done);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -171,6 +179,11 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
   alloc(reinterpret_cast<void **>(&c->d_out), sizeof(float) * np * h.out_dim);
   alloc(reinterpret_cast<void **>(&c->d_partial), sizeof(float) * npt * (max_rows_pad / fdnn::kPartialNodes));
   alloc(reinterpret_cast<void **>(&c->d_mask), np * h.out_dim);
+  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mask_pin), size_t(kPinFrames) * h.out_dim, hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_mask_pin), c->h_mask_pin, 0);
+  if (e == hipSuccess)
+    e = hipHostMalloc(reinterpret_cast<void **>(&c->h_out_pin), sizeof(float) * kPinFrames * h.out_dim, hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_out_pin), c->h_out_pin, 0);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -305,7 +318,8 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
 // over frames [first, first+count) of the context's last hidden activations.
 // Rows [first+count, first+n_pad) are read by the GEMM as padding frames; the
 // activation buffers carry one tile of slack rows for that.
-int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out, hipStream_t s, const Taps *taps) {
+int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out, hipStream_t s, const Taps *taps,
+               float *d_final = nullptr) {  // d_final: where the probabilities go (default: in place in d_out)
   fdnn_model *m = c->m;
   const BlobHeader &h = m->hm.hdr;
   const QLayerDesc &d = h.q[h.n_q - 1];
@@ -325,7 +339,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   }
   {
     ProfScope ps(m, s, FDNN_PROF_NORMALIZE);
-    fdnn::launch_normalize(d_out, c->d_partial, count, g.partial_ld, d.rows, d.rows_pad / fdnn::kPartialNodes, s);
+    fdnn::launch_normalize(d_out, d_final ? d_final : d_out, c->d_partial, count, g.partial_ld, d.rows, d.rows_pad / fdnn::kPartialNodes, s);
   }
   HIP_TRY(hipGetLastError());
   return FDNN_OK;
@@ -505,6 +519,14 @@ int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *
   DeviceGuard g(c->m->device);
   const BlobHeader &h = c->m->hm.hdr;
   const size_t O = size_t(h.out_dim);
+  if (count <= kPinFrames) {  // the per-frame protocol: no copy commands (see fdnn_ctx)
+    std::memcpy(c->h_mask_pin, masks, size_t(count) * O);
+    int rc = run_output(c, first, count, c->d_mask_pin, c->d_out, c->stream, nullptr, c->d_out_pin);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::memcpy(out, c->h_out_pin, sizeof(float) * size_t(count) * O);
+    return FDNN_OK;
+  }
   HIP_TRY(hipMemcpyAsync(c->d_mask, masks, size_t(count) * O, hipMemcpyHostToDevice, c->stream));
   int rc = run_output(c, first, count, c->d_mask, c->d_out, c->stream, nullptr);
   if (rc) return rc;
