@@ -63,6 +63,22 @@ struct QGemmParams {
 void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s);
 void launch_qgemm_output(const QGemmParams &p, hipStream_t s);
 
+// One frame of the lazy output layer (the per-frame JNI call): exp(z) of every node into
+// e_out[rows], the 64-node partial sums into partial[rows_pad/64] in the batched kernel's
+// summation order; launch_normalize(e_out, dst, partial, 1, 1, ...) finishes the soft-max.
+struct LazyFrameParams {
+  const int8_t *w;      // [rows_pad][ldw]
+  const int8_t *a;      // the frame's activation row, s8 = u8 - 128, K bytes
+  const float *bias;    // [rows_pad]
+  const int8_t *mask;   // [rows_pad readable] non-zero = active (may be host-mapped)
+  float *e_out;         // [rows]
+  float *partial;       // [rows_pad / 64]
+  int rows, rows_pad, K, ldw;
+  float coef, rcp_coef;
+  int fastdiv;
+};
+void launch_lazy_frame(const LazyFrameParams &p, hipStream_t s);
+
 // dst[f][:] = out[f][:] / sum_t partial[t][f]   (dst == out: in place; dst may be host-mapped)
 void launch_normalize(float *out, float *dst, const float *partial, int n, int partial_ld, int rows, int n_partial, hipStream_t s);
 

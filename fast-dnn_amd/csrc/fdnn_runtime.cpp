@@ -179,7 +179,8 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
   alloc(reinterpret_cast<void **>(&c->d_out), sizeof(float) * np * h.out_dim);
   alloc(reinterpret_cast<void **>(&c->d_partial), sizeof(float) * npt * (max_rows_pad / fdnn::kPartialNodes));
   alloc(reinterpret_cast<void **>(&c->d_mask), np * h.out_dim);
-  if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mask_pin), size_t(kPinFrames) * h.out_dim, hipHostMallocMapped);
+  if (e == hipSuccess)  // at least one padded row: the one-frame kernel reads the mask in 16-byte pieces up to rows_pad
+    e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mask_pin), std::max(size_t(kPinFrames) * h.out_dim, size_t(max_rows_pad)), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_mask_pin), c->h_mask_pin, 0);
   if (e == hipSuccess)
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_out_pin), sizeof(float) * kPinFrames * h.out_dim, hipHostMallocMapped);
@@ -521,7 +522,36 @@ int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *
   const size_t O = size_t(h.out_dim);
   if (count <= kPinFrames) {  // the per-frame protocol: no copy commands (see fdnn_ctx)
     std::memcpy(c->h_mask_pin, masks, size_t(count) * O);
-    int rc = run_output(c, first, count, c->d_mask_pin, c->d_out, c->stream, nullptr, c->d_out_pin);
+    int rc = FDNN_OK;
+    if (count == 1) {  // one frame: a row-times-matrix kernel instead of a 128-frame GEMM tile
+      const QLayerDesc &d = h.q[h.n_q - 1];
+      const uint8_t *B = c->m->d_blob;
+      fdnn::LazyFrameParams lp{};
+      lp.w = reinterpret_cast<const int8_t *>(B + d.off_w);
+      lp.a = c->d_act[c->last] + size_t(first) * c->act_ld;
+      lp.bias = reinterpret_cast<const float *>(B + d.off_bias);
+      lp.mask = c->d_mask_pin;
+      lp.e_out = c->d_out;
+      lp.partial = c->d_partial;
+      lp.rows = d.rows;
+      lp.rows_pad = d.rows_pad;
+      lp.K = d.cols_pad - fdnn::kRowSkew;
+      lp.ldw = d.cols_pad;
+      lp.coef = d.coef;
+      lp.rcp_coef = d.rcp_coef;
+      lp.fastdiv = d.fastdiv_ok;
+      {
+        ProfScope ps(c->m, c->stream, FDNN_PROF_OUTPUT);
+        fdnn::launch_lazy_frame(lp, c->stream);
+      }
+      {
+        ProfScope ps(c->m, c->stream, FDNN_PROF_NORMALIZE);
+        fdnn::launch_normalize(c->d_out, c->d_out_pin, c->d_partial, 1, 1, d.rows, d.rows_pad / fdnn::kPartialNodes, c->stream);
+      }
+      HIP_TRY(hipGetLastError());
+    } else {
+      rc = run_output(c, first, count, c->d_mask_pin, c->d_out, c->stream, nullptr, c->d_out_pin);
+    }
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::memcpy(out, c->h_out_pin, sizeof(float) * size_t(count) * O);

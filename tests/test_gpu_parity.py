@@ -357,6 +357,41 @@ def test_shard_of_the_million_frame_config(net_model_path):
     dnn.delete()
 
 
+def test_one_frame_lazy_kernel_equals_the_batched_path(net_model_path, sat_model_path):
+    """The per-frame JNI call runs a row-times-matrix kernel (pmaddubsw pairs computed directly);
+    it must give bit-for-bit what the MFMA path gives for the same frame, and the oracle's
+    LazyOutputActivations numbers -- on the full 2048 -> 8000 layer and on the net whose pairs
+    really saturate."""
+    x = F.synth_features(24, 432, seed=41)
+    masks = F.generate_masks(24, 8000, 0.40, 0.03, seed=5)
+    masks[3] = 0   # nothing active: every node comes back as 1/8000
+    masks[4] = 1   # everything active
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    ctx = dnn.getNewLazyContext(24)
+    ctx.calculateUntilOutput(x)
+    batch = ctx.calculateForOutputNodesBatch(masks)            # 24 > 8 frames: the GEMM path
+    rows = np.stack([ctx.calculateForOutputNodes(masks[i]) for i in range(24)])
+    assert (rows == batch).all()
+    assert np.allclose(rows[3], 1.0 / 8000, rtol=0, atol=1e-9)
+    want = Oracle(net_model_path).lazy(x[:6], masks[:6])
+    assert np.abs(rows[:6] - want).max() <= TIGHT
+    ctx.delete()
+    dnn.delete()
+
+    g = golden("sat.npz")
+    dnn = api.QuantizedDnn.loadFromFile(sat_model_path)
+    xs = g["x"]
+    n, O = xs.shape[0], dnn.outputDimension()
+    ones = np.ones((n, O), np.int8)
+    ctx = dnn.getNewLazyContext(n)
+    ctx.calculateUntilOutput(xs)
+    rows = np.stack([ctx.calculateForOutputNodes(ones[i]) for i in range(n)])
+    assert np.abs(rows - g["probs"]).max() <= TIGHT            # all-active lazy == dense, saturation included
+    assert (rows == dnn.calculate(xs)).all() or np.abs(rows - dnn.calculate(xs)).max() <= 1e-9
+    ctx.delete()
+    dnn.delete()
+
+
 def test_device_pointer_lazy_api(mid_model_path, x16):
     """fdnn_ctx_forward_hidden_device / fdnn_ctx_lazy_output_batch_device: same numbers as the
     host-pointer calls, buffers owned by the caller (torch only provides the device memory)."""
