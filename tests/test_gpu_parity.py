@@ -357,6 +357,30 @@ def test_shard_of_the_million_frame_config(net_model_path):
     dnn.delete()
 
 
+@pytest.mark.parametrize("hidden", [64, 144, 400])
+def test_big_batch_small_net_takes_the_8_wave_shapes(tmp_models, hidden):
+    """Enough frames that the 256/320-frame, 8-wave kernel shapes (rotated-barrier k-loop) are
+    chosen, with k-loops of only 1, 2 and 4 steps: prologue/refill edge cases of that loop."""
+    import os
+
+    p = os.path.join(tmp_models, f"wide_batch_h{hidden}.bin")
+    F.write_model_bin(p, F.synth_net([432, hidden, hidden, hidden, 300], seed=40 + hidden))
+    n = 40000  # one 256-node tile needs > 32 768 frames before the 128-frame shape stops being chosen
+    x = F.synth_features(n, 432, seed=12)
+    want, wt = Oracle(p).calculate(x, taps=True)
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    got = dnn.calculate(x)
+    assert np.abs(got - want).max() <= TIGHT
+    t = dnn.forwardTaps(x[:700])  # taps for a slice (the tap kernels are separate instances)
+    assert (t["u8_acts"] == wt["u8_acts"][:, :700]).all()
+    assert (t["acc_out"] == wt["acc_out"][:700]).all()
+    ctx = dnn.getNewLazyContext(n)
+    ctx.calculateUntilOutput(x)
+    assert (ctx.hiddenActivations() == wt["u8_acts"][-1]).all()   # last hidden layer, all 40 000 frames, bit for bit
+    ctx.delete()
+    dnn.delete()
+
+
 def test_one_frame_lazy_kernel_equals_the_batched_path(net_model_path, sat_model_path):
     """The per-frame JNI call runs a row-times-matrix kernel (pmaddubsw pairs computed directly);
     it must give bit-for-bit what the MFMA path gives for the same frame, and the oracle's
