@@ -225,6 +225,218 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float *base
 }
 #endif
 
+// ---------------------------------------------------------------- VALU, one chain per pass (canonical flavour)
+// The four k-mod-4 chains of an output are independent until (l0+l1)+(l2+l3), so a tile can
+// run them one after the other: pass c walks k = c, c+4, c+8, ... with ONE accumulator per
+// output instead of four.  That buys an 8 x 8 output block per thread at 64 accumulators, i.e.
+// 4 ds_read_b128 per 64 MACs = 1 LDS byte per MAC; the 4 x 4 x (4 chains) kernel above needs 2,
+// which at the packed-fp32 rate (64 MAC/clk/CU) is the whole 128 B/clk of the LDS.
+//
+// Operands come as chain-major images  img[c][j][column] = src[column][4j + c]  (column = frame
+// or node): a stage is JC rows of 128 frames and JC rows of 128 nodes, every row 512 contiguous
+// bytes -> LDS-DMA, no VGPR round trip, no VALU work outside the MACs.  The frame image (with
+// ApplyShiftAndScale folded in) is written by l0_image_kernel before every launch (17 MB in,
+// 17 MB out), the weight image once at model load.
+//
+// 256 threads = 16 (tx: nodes) x 16 (ty: frames); thread owns frames {4ty..4ty+3, 64+4ty..} and
+// nodes {4tx..4tx+3, 64+4tx..}; frame pairs ride v_pk_mul_f32 / v_pk_add_f32.
+template <int JC, bool TAP>
+__global__ __launch_bounds__(256, 2) void l0_chain_kernel(L0Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins are device-only
+  constexpr int TF = 128, TN = 128, NST = 3;
+  constexpr int STAGE_F = JC * (TF + TN);  // floats per stage
+  constexpr int NLD = JC / 4;              // 1-KiB loads per wave and stage: JC/2 frame row pairs + JC/2 node row pairs
+  static_assert(JC % 4 == 0, "a stage is split evenly over four waves");
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // NST stages, then the sigmoid table
+  uint8_t *lut = reinterpret_cast<uint8_t *>(smem + NST * STAGE_F);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tx = tid & 15, ty = tid >> 4;
+  int bx, by;
+  if (!l0_tile_of_block(p.h_ld / TN, (p.n_rows + TF - 1) / TF, bx, by)) return;
+  const int f0 = by * TF, n0 = bx * TN;
+  if (tid < (kLutExt + 15) / 16) reinterpret_cast<uint4 *>(lut)[tid] = reinterpret_cast<const uint4 *>(p.lut)[tid];
+
+  const int NQ = p.j_pad / JC, NS = 4 * NQ;  // stage s = (pass s / NQ, chunk s % NQ): image row s * JC
+  const int voff_x = ((lane >> 5) * p.n_ld + (lane & 31) * 4) * 4;
+  const int voff_w = ((lane >> 5) * p.h_ld + (lane & 31) * 4) * 4;
+  const size_t x_ld = static_cast<size_t>(p.n_ld), w_ld = static_cast<size_t>(p.h_ld);
+  auto issue = [&](int s, int buf) {
+    const size_t row0 = static_cast<size_t>(s) * JC;
+    const auto rsrc_x = uniform_rsrc(p.xt + row0 * x_ld + f0, JC * p.n_ld * 4);
+    const auto rsrc_w = uniform_rsrc(p.wt + row0 * w_ld + n0, JC * p.h_ld * 4);
+    float *base = smem + buf * STAGE_F;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int u = i * 4 + wave;
+      if (u < JC / 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, FDNN_LDS_PTR(base + u * 256), 16, voff_x, u * 2 * p.n_ld * 4, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, FDNN_LDS_PTR(base + JC * TF + (u - JC / 2) * 256), 16, voff_w,
+                                                 (u - JC / 2) * 2 * p.h_ld * 4, 0, 0);
+    }
+  };
+
+  // Pass order 2, 3, 0, 1 (the images store their planes in that order): l2 waits in registers
+  // while l3 runs, t = l2 + l3 is parked in global scratch (64 KB per tile, read back from L2
+  // two passes later), l0 waits while l1 runs -> never more than two 64-register sets live.
+  v2f acc[8][4], held[8][4];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = held[a][b] = v2f{0.0f, 0.0f};
+  v2f *park = reinterpret_cast<v2f *>(p.park) + (static_cast<size_t>(by) * (p.h_ld / TN) + bx) * (32 * 256) + tid;
+
+  issue(0, 0);
+  if (NS > 1) issue(1, 1);
+  int buf = 0, q = 0, pass = 0;
+  for (int s = 0; s < NS; ++s) {
+    // this wave's share of stage s has landed (stage s+1 may still be in flight) ...
+    if (s + 1 < NS)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... and everybody's has; every wave is also done with stage s-1, whose buffer stage s+2 takes
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (s + 2 < NS) issue(s + 2, buf >= 1 ? buf - 1 : NST - 1);
+    const float *xb = smem + buf * STAGE_F, *wb = xb + JC * TF;
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      const v4f xa = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(xb) + (j * TF + ty * 4) * 4);
+      const v4f xc = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(xb) + (j * TF + 64 + ty * 4) * 4);
+      const v4f wa = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(wb) + (j * TN + tx * 4) * 4);
+      const v4f wc = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(wb) + (j * TN + 64 + tx * 4) * 4);
+      const v2f xp[4] = {{xa.x, xa.y}, {xa.z, xa.w}, {xc.x, xc.y}, {xc.z, xc.w}};
+      const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wc.x, wc.y, wc.z, wc.w};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        // InputActivations, canonical flavour: multiply and add rounded separately (dnn.cc:233-238);
+        // eight products first, so that no add waits on the multiply right before it
+        v2f pr[2][4];
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) pr[e][b] = v2f{wv[2 * g + e], wv[2 * g + e]} * xp[b];
+        asm volatile("" : "+v"(pr[0][0]), "+v"(pr[0][1]), "+v"(pr[0][2]), "+v"(pr[0][3]), "+v"(pr[1][0]), "+v"(pr[1][1]),
+                     "+v"(pr[1][2]), "+v"(pr[1][3]));
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[2 * g + e][b] += pr[e][b];
+      }
+    }
+    buf = buf + 1 == NST ? 0 : buf + 1;
+    if (++q == NQ) {  // end of a pass; horizontalSum is (l0+l1)+(l2+l3) (dnn.cc:168-172)
+      q = 0;
+      if (pass == 0 || pass == 2) {  // l2 / l0 done: hold it, start l3 / l1 from zero
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            held[a][b] = acc[a][b];
+            acc[a][b] = v2f{0.0f, 0.0f};
+          }
+      } else if (pass == 1) {  // t = l2 + l3 -> scratch
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            park[(a * 4 + b) * 256] = held[a][b] + acc[a][b];
+            acc[a][b] = v2f{0.0f, 0.0f};
+          }
+      }
+      ++pass;
+    }
+  }
+  // held = l0, acc = l1.  AddBias + QuantizedSigmoid; node quads go out as one dword per frame.
+  float bias[8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int node = n0 + (a >> 2) * 64 + tx * 4 + (a & 3);
+    bias[a] = node < p.H ? p.bias[node] : 0.0f;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    v2f lin2[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) lin2[a] = (held[a][b] + acc[a][b]) + park[(a * 4 + b) * 256];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int f = f0 + (b >> 1) * 64 + ty * 4 + (b & 1) * 2 + h;
+      if (f >= p.n_rows) continue;
+#pragma unroll
+      for (int grp = 0; grp < 2; ++grp) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int a = grp * 4 + e;
+          const float lin = (h ? lin2[a].y : lin2[a].x) + bias[a];
+          const int node = n0 + grp * 64 + tx * 4 + e;
+          if (TAP && f < p.n && node < p.H) p.tap_lin[static_cast<size_t>(f) * p.H + node] = lin;
+          packed |= static_cast<uint32_t>(lut[lut_index(lin)]) << (8 * e);
+        }
+        // act_ld == h_ld: the pad nodes of the last tile land in the row's pad columns
+        *reinterpret_cast<uint32_t *>(p.act_out + static_cast<size_t>(f) * p.act_ld + n0 + grp * 64 + tx * 4) = packed;
+      }
+    }
+  }
+#endif
+}
+
+// Chain-major image of a row-major matrix: dst[(c + 2) % 4][j][col] = src[col][4j + c] (+ shift, * scale
+// when given: ApplyShiftAndScale, add then multiply, dnn.cc:184-187); rows j >= D/4 and columns
+// >= n_src are zero (a zero product leaves a chain untouched).  64 x 64 tiles through LDS.
+__global__ __launch_bounds__(256) void l0_image_kernel(const float *src, const float *shift, const float *scale, float *dst,
+                                                       int n_src, int D, int j_pad, int ld) {
+  __shared__ float t[64][65];
+  const int tid = threadIdx.x, lo = tid & 15, hi = tid >> 4;
+  const int col0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = hi + 16 * i, k = k0 + lo * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col0 + r < n_src && k < D) {  // D is a multiple of 4
+      v = *reinterpret_cast<const float4 *>(src + static_cast<size_t>(col0 + r) * D + k);
+      if (shift) {
+        const float4 sh = *reinterpret_cast<const float4 *>(shift + k);
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + k);
+        v.x = (v.x + sh.x) * sc.x;
+        v.y = (v.y + sh.y) * sc.y;
+        v.z = (v.z + sh.z) * sc.z;
+        v.w = (v.w + sh.w) * sc.w;
+      }
+    }
+    t[r][lo * 4 + 0] = v.x;
+    t[r][lo * 4 + 1] = v.y;
+    t[r][lo * 4 + 2] = v.z;
+    t[r][lo * 4 + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int kl = hi + 16 * i, c = ((kl & 3) + 2) & 3, j = (k0 >> 2) + (kl >> 2);  // planes in pass order: chains 2, 3, 0, 1
+    if (j >= j_pad) continue;
+    const float4 v = make_float4(t[lo * 4 + 0][kl], t[lo * 4 + 1][kl], t[lo * 4 + 2][kl], t[lo * 4 + 3][kl]);
+    *reinterpret_cast<float4 *>(dst + (static_cast<size_t>(c) * j_pad + j) * ld + col0 + lo * 4) = v;
+  }
+}
+
+template <int JC>
+void launch_chain(const L0Params &p, hipStream_t s) {
+  const int cols = (p.n_rows + 127) / 128 * 128;
+  hipLaunchKernelGGL(l0_image_kernel, dim3(cols / 64, (p.j_pad * 4 + 63) / 64), dim3(256), 0, s, p.x, p.shift, p.scale, p.xt, p.n,
+                     p.D, p.j_pad, p.n_ld);
+  dim3 grid(l0_grid(p.h_ld / 128, cols / 128));
+  constexpr size_t lds = sizeof(float) * (3 * JC * 256 + (kLutExt + 15) / 16 * 4);
+  if (p.tap_lin)
+    hipLaunchKernelGGL((l0_chain_kernel<JC, true>), grid, dim3(256), lds, s, p);
+  else
+    hipLaunchKernelGGL((l0_chain_kernel<JC, false>), grid, dim3(256), lds, s, p);
+}
+
 template <int BK, int WFR>
 struct L0MfmaCfg {
   static constexpr int TF = 32 * WFR, TN = 128, LD = BK + 2, QPR = BK / 4, THREADS = 128 * WFR;
@@ -388,30 +600,32 @@ void launch_mfma(const L0Params &p, hipStream_t s) {
 void launch_l0(const L0Params &p, hipStream_t s) {
   static const bool fma_on_valu = std::getenv("FDNN_L0_FMA_VALU") != nullptr;
   if (p.fma && !fma_on_valu) {
-    static const int bk = [] {
-      const char *e = std::getenv("FDNN_L0_MFMA_BK");
-      return e ? std::atoi(e) : 324;
-    }();
-    switch (bk) {  // BK * 10 + WFR
-      case 164: launch_mfma<16, 4>(p, s); break;
-      case 644: launch_mfma<64, 4>(p, s); break;
-      case 162: launch_mfma<16, 2>(p, s); break;
-      case 642: launch_mfma<64, 2>(p, s); break;
-      case 322: launch_mfma<32, 2>(p, s); break;
-      default: launch_mfma<32, 4>(p, s); break;
-    }
+    // 32-float chunks, 4 x 2 waves (128 x 128 tile).  Measured alternatives at 10 000 frames:
+    // 16-float chunks 0.221 ms, 64-float 0.205, 256-thread workgroups (two per CU) 0.205.
+    launch_mfma<32, 4>(p, s);
     return;
   }
-  static const int variant = [] {
-    const char *e = std::getenv("FDNN_L0_VARIANT");
-    return e ? std::atoi(e) : 0;
-  }();
-  switch (variant) {
-    case 1: launch_valu<4, 32>(p, s); break;
-    case 2: launch_valu<8, 16>(p, s); break;
-    case 3: launch_valu<8, 32>(p, s); break;
-    default: launch_valu<4, 16>(p, s); break;
+  static const bool classic = std::getenv("FDNN_L0_CLASSIC") != nullptr;
+  if (!p.fma && !classic && p.xt && p.wt) {
+    if (p.jc == 12)
+      launch_chain<12>(p, s);
+    else
+      launch_chain<16>(p, s);
+    return;
   }
+  // 64 x 64 tile, 16-float chunks, 4 x 4 outputs per thread.  Measured alternatives: 32-float
+  // chunks 0.448 ms, 8 x 4 outputs per thread 0.468 / 0.477 ms (occupancy 2) against 0.388.
+  launch_valu<4, 16>(p, s);
+}
+
+int l0_chunk_rows(int D) {
+  const int J = D / 4, p12 = (J + 11) / 12 * 12, p16 = (J + 15) / 16 * 16;
+  return p12 <= p16 ? 12 : 16;
+}
+
+void launch_l0_weight_image(const float *w, float *wt, int H, int D, int j_pad, int h_ld, hipStream_t s) {
+  hipLaunchKernelGGL(l0_image_kernel, dim3(h_ld / 64, (j_pad * 4 + 63) / 64), dim3(256), 0, s, w, nullptr, nullptr, wt, H, D, j_pad,
+                     h_ld);
 }
 
 }  // namespace fdnn

@@ -46,6 +46,8 @@ struct fdnn_model {
   fdnn::HostModel hm;  // header + host copy of the blob (kept: export, host queries)
   int device = 0;
   uint8_t *d_blob = nullptr;
+  float *d_w0t = nullptr;  // layer-0 weights as a chain-major image [4][l0_j_pad][l0_h_ld] (fdnn_l0.hip)
+  int l0_jc = 0, l0_j_pad = 0, l0_h_ld = 0;
   int l0_fma = 0;
   std::mutex mu;
   std::vector<fdnn_ctx *> pool;  // idle contexts owned by the model (fdnn_calculate*)
@@ -66,6 +68,9 @@ struct fdnn_ctx {
   hipStream_t stream = nullptr;   // own stream for the host-pointer entry points
   hipEvent_t done = nullptr;      // last enqueued work (pool hand-over between streams)
   float *d_x = nullptr;           // [n][D]
+  float *d_xt = nullptr;          // [4][l0_j_pad][xt_ld] layer-0 frame image (shifted, scaled, chain-major)
+  int xt_ld = 0;
+  float *d_l0park = nullptr;      // [xt_ld][l0_h_ld] partial chain sums parked by the layer-0 kernel
   int8_t *d_act[2] = {nullptr, nullptr};  // [n_pad][act_ld] ping/pong, s8 = u8-128
   float *d_out = nullptr;         // [n][O]
   float *d_partial = nullptr;     // [rows_pad/64][n_pad]
@@ -95,6 +100,8 @@ struct DeviceGuard {
     if (ok) hipSetDevice(prev);
   }
 };
+
+int build_l0_image(fdnn_model *m);
 
 int upload_model(fdnn_model *m) {
   int count = 0;
@@ -132,6 +139,20 @@ int upload_model(fdnn_model *m) {
   }
   std::memcpy(m->hm.blob.data(), &h, sizeof(h));
   HIP_TRY(hipMemcpy(m->d_blob, m->hm.blob.data(), m->hm.blob.size(), hipMemcpyHostToDevice));
+  return build_l0_image(m);
+}
+
+// Layer-0 weight image for the chain-pass kernel, built on the device from the blob's [H][D] rows.
+int build_l0_image(fdnn_model *m) {
+  const BlobHeader &h = m->hm.hdr;
+  m->l0_jc = fdnn::l0_chunk_rows(h.in_dim);
+  m->l0_j_pad = round_up(h.in_dim / 4, m->l0_jc);
+  m->l0_h_ld = round_up(h.hidden, 128);
+  HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_w0t), sizeof(float) * 4 * size_t(m->l0_j_pad) * m->l0_h_ld));
+  fdnn::launch_l0_weight_image(reinterpret_cast<const float *>(m->d_blob + h.off_w0), m->d_w0t, h.hidden, h.in_dim, m->l0_j_pad,
+                               m->l0_h_ld, nullptr);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
   return FDNN_OK;
 }
 
@@ -140,6 +161,8 @@ void destroy_ctx(fdnn_ctx *c) {
   DeviceGuard g(c->m->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   hipFree(c->d_x);
+  hipFree(c->d_xt);
+  hipFree(c->d_l0park);
   hipFree(c->d_act[0]);
   hipFree(c->d_act[1]);
   hipFree(c->d_out);
@@ -174,6 +197,9 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
     if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16);
   };
   alloc(reinterpret_cast<void **>(&c->d_x), sizeof(float) * np * h.in_dim);
+  c->xt_ld = round_up(c->cap, 128);
+  alloc(reinterpret_cast<void **>(&c->d_xt), sizeof(float) * 4 * size_t(m->l0_j_pad) * c->xt_ld);
+  alloc(reinterpret_cast<void **>(&c->d_l0park), sizeof(float) * size_t(c->xt_ld) * m->l0_h_ld);
   alloc(reinterpret_cast<void **>(&c->d_act[0]), npt * c->act_ld);
   alloc(reinterpret_cast<void **>(&c->d_act[1]), npt * c->act_ld);
   alloc(reinterpret_cast<void **>(&c->d_out), sizeof(float) * np * h.out_dim);
@@ -292,6 +318,13 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
   l0.D = h.in_dim;
   l0.H = h.hidden;
   l0.fma = m->l0_fma;
+  l0.xt = c->d_xt;
+  l0.wt = m->d_w0t;
+  l0.park = c->d_l0park;
+  l0.j_pad = m->l0_j_pad;
+  l0.jc = m->l0_jc;
+  l0.n_ld = c->xt_ld;
+  l0.h_ld = m->l0_h_ld;
   {
     ProfScope ps(m, s, FDNN_PROF_L0);
     fdnn::launch_l0(l0, s);
@@ -419,6 +452,7 @@ int fdnn_model_load_on(const char *path, float cutoff, int device, fdnn_model **
   rc = upload_model(m);
   if (rc) {
     if (m->d_blob) hipFree(m->d_blob);
+    if (m->d_w0t) hipFree(m->d_w0t);
     delete m;
     return rc;
   }
@@ -439,6 +473,7 @@ void fdnn_model_free(fdnn_model *m) {
   {
     DeviceGuard g(m->device);
     hipFree(m->d_blob);
+    hipFree(m->d_w0t);
   }
   delete m;
 }
@@ -777,6 +812,13 @@ int fdnn_model_import_blob(const void *d_src, size_t bytes, int device, fdnn_mod
     if (m->d_blob) hipFree(m->d_blob);
     delete m;
     return fail(FDNN_E_DEVICE, std::string("blob import: ") + hipGetErrorString(e));
+  }
+  rc = build_l0_image(m);
+  if (rc) {
+    hipFree(m->d_blob);
+    if (m->d_w0t) hipFree(m->d_w0t);
+    delete m;
+    return rc;
   }
   *out = m;
   return FDNN_OK;
