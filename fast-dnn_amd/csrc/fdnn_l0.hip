@@ -209,8 +209,12 @@ void launch_valu(const L0Params &p, hipStream_t s) {
 // (table + stores) overlap the other's MFMA stream.
 typedef float v32f __attribute__((ext_vector_type(32)));
 
+#ifndef FDNN_L0_SCHED_MASK
+#define FDNN_L0_SCHED_MASK 0x3f4  // what may cross the products | adds fence of the chain kernel: memory and scalar ops
+#endif
 #ifndef FDNN_L0_DEBUG
-#define FDNN_L0_DEBUG 0  // kernel-ablation timing builds only (tools/build_variant.sh): 1 no MFMA, 2 no loads in the k-loop
+#define FDNN_L0_DEBUG 0  // kernel-ablation timing builds only (tools/build_variant.sh): 1 no MFMA, 2 no loads in the k-loop;
+                         // chain kernel: 4 operands from registers (no LDS reads), 8 no LDS-DMA in the loop
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -290,6 +294,10 @@ __global__ __launch_bounds__(256, 2) void l0_chain_kernel(L0Params p) {
 
   issue(0, 0);
   if (NS > 1) issue(1, 1);
+#if FDNN_L0_DEBUG & 4
+  typedef float v4f_dbg __attribute__((ext_vector_type(4)));
+  const v4f_dbg dbg_x = {float(tid), 1.0f, 2.0f, 3.0f}, dbg_w = {0.5f, float(lane), 0.25f, 2.0f};
+#endif
   int buf = 0, q = 0, pass = 0;
   for (int s = 0; s < NS; ++s) {
     // this wave's share of stage s has landed (stage s+1 may still be in flight) ...
@@ -300,15 +308,21 @@ __global__ __launch_bounds__(256, 2) void l0_chain_kernel(L0Params p) {
     // ... and everybody's has; every wave is also done with stage s-1, whose buffer stage s+2 takes
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (s + 2 < NS) issue(s + 2, buf >= 1 ? buf - 1 : NST - 1);
+    if (!(FDNN_L0_DEBUG & 8) && s + 2 < NS) issue(s + 2, buf >= 1 ? buf - 1 : NST - 1);
     const float *xb = smem + buf * STAGE_F, *wb = xb + JC * TF;
 #pragma unroll
     for (int j = 0; j < JC; ++j) {
       typedef float v4f __attribute__((ext_vector_type(4)));
+#if FDNN_L0_DEBUG & 4
+      static_assert(sizeof(v4f) == 16, "");
+      v4f xa = dbg_x, xc = dbg_x, wa = dbg_w, wc = dbg_w;
+      asm volatile("" : "+v"(xa), "+v"(xc), "+v"(wa), "+v"(wc));
+#else
       const v4f xa = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(xb) + (j * TF + ty * 4) * 4);
       const v4f xc = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(xb) + (j * TF + 64 + ty * 4) * 4);
       const v4f wa = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(wb) + (j * TN + tx * 4) * 4);
       const v4f wc = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(wb) + (j * TN + 64 + tx * 4) * 4);
+#endif
       const v2f xp[4] = {{xa.x, xa.y}, {xa.z, xa.w}, {xc.x, xc.y}, {xc.z, xc.w}};
       const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wc.x, wc.y, wc.z, wc.w};
 #pragma unroll
@@ -320,12 +334,12 @@ __global__ __launch_bounds__(256, 2) void l0_chain_kernel(L0Params p) {
         for (int e = 0; e < 2; ++e)
 #pragma unroll
           for (int b = 0; b < 4; ++b) pr[e][b] = v2f{wv[2 * g + e], wv[2 * g + e]} * xp[b];
-        asm volatile("" : "+v"(pr[0][0]), "+v"(pr[0][1]), "+v"(pr[0][2]), "+v"(pr[0][3]), "+v"(pr[1][0]), "+v"(pr[1][1]),
-                     "+v"(pr[1][2]), "+v"(pr[1][3]));
+        __builtin_amdgcn_sched_barrier(FDNN_L0_SCHED_MASK);
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
           for (int b = 0; b < 4; ++b) acc[2 * g + e][b] += pr[e][b];
+        __builtin_amdgcn_sched_barrier(FDNN_L0_SCHED_MASK);
       }
     }
     buf = buf + 1 == NST ? 0 : buf + 1;
