@@ -297,6 +297,27 @@ def test_hidden_widths_not_multiple_of_the_k_step(tmp_models, hidden):
     dnn.delete()
 
 
+@pytest.mark.parametrize("in_dim,frames", [(20, 129), (64, 77), (100, 300), (440, 256), (448, 130)])
+def test_input_widths_and_the_chain_image_padding(tmp_models, in_dim, frames):
+    """Layer 0 runs on chain-major images padded to whole 12- or 16-row chunks and 128-column
+    tiles (fdnn_l0.hip): widths that pick either chunk depth, with and without a zero tail, and
+    frame counts around the 128-frame tile must give the reference's layer-0 sums bit for bit."""
+    import os
+
+    p = os.path.join(tmp_models, f"in{in_dim}.bin")
+    F.write_model_bin(p, F.synth_net([in_dim, 144, 144, 144, 40], seed=60 + in_dim))
+    x = F.synth_features(frames, in_dim, seed=in_dim)
+    want, wt = Oracle(p).calculate(x, taps=True)
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    t = dnn.forwardTaps(x)
+    assert np.array_equal(t["l0_lin"].view(np.uint32), wt["l0_lin"].view(np.uint32))
+    assert (t["u8_acts"] == wt["u8_acts"]).all()
+    assert np.abs(t["probs"] - want).max() <= TIGHT
+    # production kernels (no taps) agree with the tapped instance
+    assert np.array_equal(dnn.calculate(x), t["probs"])
+    dnn.delete()
+
+
 def test_cli_matches_oracle(tmp_path, mid_model_path, x16):
     """fast-dnn model input out BIN|TXT (dnn.cc:20-84): big-endian input matrix, host-endian
     u32-header BIN output, one text row per frame."""
