@@ -57,6 +57,7 @@ SIGNATURES = {
     "fdnn_model_layer_dim": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_model_device": (C.c_int, [C.c_void_p]),
     "fdnn_model_set_l0_fma": (C.c_int, [C.c_void_p, C.c_int]),
+    "fdnn_debug_set_l0_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_calculate": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, C.c_int, _c_f32p]),
     "fdnn_calculate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "fdnn_ctx_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -259,6 +260,10 @@ class QuantizedDnn:
 
     def setInputLayerFma(self, on: bool) -> None:
         _check(lib().fdnn_model_set_l0_fma(self.nativeDnnHandle, int(on)))
+
+    def setInputLayerKernel(self, kind: int) -> None:
+        """0 = chosen by batch size, 1 = chain-pass kernel, 2 = 64 x 64-tile kernel (same bits)."""
+        _check(lib().fdnn_debug_set_l0_kernel(self.nativeDnnHandle, int(kind)))
 
     # -- dense path ---------------------------------------------------------
     def calculate(self, input, batchSize: int = 10) -> np.ndarray:

@@ -23,6 +23,7 @@ struct L0Params {
   int n, D, H;
   int n_rows;          // rows of act_out to fill (>= n, the next GEMM's padded frame count)
   int fma;             // 0: mul then add (canonical), 1: fused
+  int kernel;          // canonical flavour: 0 pick by batch size, 1 chain-pass kernel, 2 64 x 64-tile kernel
   // canonical flavour: chain-major operand images  img[(c + 2) % 4][j][col] = src[col][4j + c]
   float *xt;           // [4][j_pad][n_ld] frame image, scratch, rewritten by every launch
   const float *wt;     // [4][j_pad][h_ld] weight image (launch_l0_weight_image at model load)

@@ -6,12 +6,14 @@
 // The reference accumulates FOUR partial sums per (frame, node) -- SSE lane l takes
 // k = l mod 4 -- each a sequential chain over k, combined (l0+l1)+(l2+l3)
 // (dnn.cc:233-238, :168-172).  The u8 output goes through round(100*x) and a table,
-// so one ulp matters: both kernels below reproduce those chains exactly.
+// so one ulp matters: all kernels below reproduce those chains exactly.
 //
-//   l0_valu_kernel  canonical numerics (reference built -O2 -msse4 -ffp-contract=off):
-//                   multiply and add are separate roundings -> VALU v_pk_mul_f32 +
-//                   v_pk_add_f32 (packed by hand), two lane-ops per MAC; bound by the
-//                   fp32 vector instruction rate (83 % of what a bare mul/add loop reaches).
+//   l0_chain_kernel canonical numerics (reference built -O2 -msse4 -ffp-contract=off): multiply
+//                   and add are separate roundings -> v_pk_mul_f32 + v_pk_add_f32, two lane-ops
+//                   per MAC; one chain per pass over chain-major operand images, 8 x 8 outputs
+//                   per thread (81 % of what a bare packed mul/add loop reaches).  Batches
+//                   that fill the chip with 128 x 128 tiles.
+//   l0_valu_kernel  same numerics, 64 x 64 tiles, all four chains at once: smaller batches.
 //   l0_mfma_kernel  the reference as its own Makefile builds it on an FMA host
 //                   (-march=native contracts mul+add): each chain is an fmaf chain,
 //                   which is bit-for-bit what one block of v_mfma_f32_32x32x1_2b_f32
@@ -620,7 +622,16 @@ void launch_l0(const L0Params &p, hipStream_t s) {
     return;
   }
   static const bool classic = std::getenv("FDNN_L0_CLASSIC") != nullptr;
-  if (!p.fma && !classic && p.xt && p.wt) {
+  // The chain kernel's 128 x 128 tiles pay off once they fill the chip: a CU turns one over in
+  // ~67 us (432 inputs) and tiles come in rounds of 256, while the 64 x 64 tiles of the classic
+  // kernel scale linearly (37.5 ns per frame of a 432 -> 2048 layer + 20 us).  Measured
+  // crossover for that layer: between 3000 and 4000 frames (tools/l0_sweep.sh).
+  const double work = static_cast<double>(p.D) / 432.0;
+  const long tiles = static_cast<long>((p.n_rows + 127) / 128) * (p.h_ld / 128);
+  const double chain_ms = 0.015 + 0.067 * work * static_cast<double>((tiles + 255) / 256);
+  const double classic_ms = 0.020 + 37.5e-6 * work * (p.H / 2048.0) * p.n_rows;
+  const bool chain = p.kernel == 1 || (p.kernel == 0 && !classic && chain_ms < classic_ms);
+  if (!p.fma && chain && p.xt && p.wt) {
     if (p.jc == 12)
       launch_chain<12>(p, s);
     else

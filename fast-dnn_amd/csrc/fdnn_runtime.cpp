@@ -49,6 +49,7 @@ struct fdnn_model {
   float *d_w0t = nullptr;  // layer-0 weights as a chain-major image [4][l0_j_pad][l0_h_ld] (fdnn_l0.hip)
   int l0_jc = 0, l0_j_pad = 0, l0_h_ld = 0;
   int l0_fma = 0;
+  int l0_kernel = 0;  // fdnn_debug_set_l0_kernel
   std::mutex mu;
   std::vector<fdnn_ctx *> pool;  // idle contexts owned by the model (fdnn_calculate*)
   // per-kernel HIP-event timing (fdnn_profile_begin/end); off in production
@@ -318,6 +319,7 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
   l0.D = h.in_dim;
   l0.H = h.hidden;
   l0.fma = m->l0_fma;
+  l0.kernel = m->l0_kernel;
   l0.xt = c->d_xt;
   l0.wt = m->d_w0t;
   l0.park = c->d_l0park;
@@ -496,6 +498,13 @@ int fdnn_model_layer_dim(const fdnn_model *m, int index) {
 int fdnn_model_set_l0_fma(fdnn_model *m, int on) {
   if (!m) return fail(FDNN_E_ARG, "null model");
   m->l0_fma = on ? 1 : 0;
+  return FDNN_OK;
+}
+
+int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind) {
+  if (!m) return fail(FDNN_E_ARG, "null model");
+  if (kind < 0 || kind > 2) return fail(FDNN_E_ARG, "layer-0 kernel kind must be 0, 1 or 2");
+  m->l0_kernel = kind;
   return FDNN_OK;
 }
 

@@ -155,6 +155,11 @@ FDNN_API int fdnn_model_import_blob(const void *d_src, size_t bytes, int device,
 FDNN_API int fdnn_debug_forward_taps(fdnn_model *m, const float *x, int n, const int8_t *masks, float *l0_lin,
                                      uint8_t *u8_acts, int32_t *acc_hid, int32_t *acc_out, float *logits, float *probs);
 
+/* Which kernel computes the canonical fp32 input layer (tests / measurements only; results are
+ * bit-identical): 0 = by batch size (default), 1 = always the chain-pass kernel (128 x 128
+ * tiles over chain-major images), 2 = always the 64 x 64-tile kernel. */
+FDNN_API int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind);
+
 /* ------------------------------------------------------------------ per-kernel timing (bench / profiling only)
  * Between begin and end every kernel launch of this model is bracketed by HIP
  * events recorded on the stream it is launched on; end() synchronizes them and

@@ -309,12 +309,14 @@ def test_input_widths_and_the_chain_image_padding(tmp_models, in_dim, frames):
     x = F.synth_features(frames, in_dim, seed=in_dim)
     want, wt = Oracle(p).calculate(x, taps=True)
     dnn = api.QuantizedDnn.loadFromFile(p)
-    t = dnn.forwardTaps(x)
-    assert np.array_equal(t["l0_lin"].view(np.uint32), wt["l0_lin"].view(np.uint32))
-    assert (t["u8_acts"] == wt["u8_acts"]).all()
-    assert np.abs(t["probs"] - want).max() <= TIGHT
-    # production kernels (no taps) agree with the tapped instance
-    assert np.array_equal(dnn.calculate(x), t["probs"])
+    for kind in (1, 2, 0):  # chain-pass kernel, 64 x 64-tile kernel, the library's own choice
+        dnn.setInputLayerKernel(kind)
+        t = dnn.forwardTaps(x)
+        assert np.array_equal(t["l0_lin"].view(np.uint32), wt["l0_lin"].view(np.uint32)), kind
+        assert (t["u8_acts"] == wt["u8_acts"]).all(), kind
+        assert np.abs(t["probs"] - want).max() <= TIGHT
+        # production kernels (no taps) agree with the tapped instance
+        assert np.array_equal(dnn.calculate(x), t["probs"]), kind
     dnn.delete()
 
 

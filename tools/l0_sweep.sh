@@ -1,6 +1,6 @@
 #!/bin/bash
 # Layer-0 time per frame at batch sizes that fill whole / partial rounds of workgroups.
-for n in 4096 8192 10000 10240 12288 16384; do
+for n in ${L0_SIZES:-4096 8192 10000 10240 12288 16384}; do
   FDNN_BENCH_NOCHECK=1 python bench.py --frames $n --steps 100 --warmup 20 --no-cpu-baseline "$@" 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
