@@ -626,7 +626,27 @@ void launch_qgemm(const QGemmParams &p, hipStream_t s) {
     launch_cfg<4, 1, 64, 3, OUTPUT, false>(p, s);
     return;
   }
+  static const int small_bk = [] {
+    const char *e = std::getenv("FDNN_SMALL_BK");
+    return e ? std::atoi(e) : 128;
+  }();
   switch (p.frame_tile) {
+    // few frames: 32- / 64-frame tiles put four / two times as many workgroups on the chip; 128-byte
+    // k-steps (3-stage ring) halve the barriers of the latency-bound loop: 16.6 vs 21 us per
+    // 2048 x 2048 layer.  What bounds these shapes is the weight tile's L2 -> LDS traffic (a
+    // 256-node tile pulls 512 KB per workgroup at ~33 B/clk/CU), not the matrix pipe.
+    case 32:
+      if (small_bk == 128)
+        launch_cfg<1, 1, 128, 3, OUTPUT>(p, s);
+      else
+        launch_cfg<1, 1, 64, 6, OUTPUT>(p, s);
+      break;
+    case 64:
+      if (small_bk == 128)
+        launch_cfg<2, 1, 128, 3, OUTPUT>(p, s);
+      else
+        launch_cfg<2, 1, 64, 6, OUTPUT>(p, s);
+      break;
     // 4 waves, 64-byte k-step, 3-stage ring, two workgroups per CU; when every workgroup has
     // a CU of its own anyway (small batches: one latency-bound k-loop per launch) a 6-stage
     // ring hides twice the load latency per step
@@ -658,12 +678,15 @@ int qgemm_frame_tile(int rows_pad, int n) {
     const char *e = std::getenv("FDNN_FRAME_TILE");
     return e ? std::atoi(e) : 0;
   }();
-  if (forced == 128 || forced == 160 || forced == 256 || forced == 320) return forced;
+  if (forced == 32 || forced == 64 || forced == 128 || forced == 160 || forced == 256 || forced == 320) return forced;
   const int mt = rows_pad / G_BM;
-  // Few frames: when even 128-frame tiles leave every workgroup a CU of its own, the launch
-  // is latency bound (one k-loop deep) and the smallest tile has the shortest k-step
-  // (measured per 2048x2048 layer, single round: 34 us at 128, 38 at 256, 41 at 160, 45 at 320).
-  if (static_cast<long>(mt) * ((n + 127) / 128) <= 256) return 128;
+  // Few frames: while every workgroup gets a CU of its own the launch is one k-loop deep and
+  // latency bound, so the smallest tile that still fits in one round wins -- it has the shortest
+  // k-step and puts the most CUs to work (2048 x 2048 layer, 1000 frames: 21 us with 32-frame
+  // tiles = 256 workgroups, 24 us at 64, 31 us at 128; 8000-node output layer, 1000 frames:
+  // 39 us at 128 = 256 workgroups, 47 us at 64, 65 us at 32 = four rounds).
+  for (int ft : {32, 64, 128})
+    if (static_cast<long>(mt) * ((n + ft - 1) / ft) <= 256) return ft;
   // Cost model: rounds x frames per tile / relative throughput of the kernel shape.
   // A round fills every CU once (two co-resident workgroups for the 4-wave shapes).
   struct Cand {

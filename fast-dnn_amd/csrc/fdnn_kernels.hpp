@@ -35,7 +35,7 @@ void launch_l0(const L0Params &p, hipStream_t s);
 int l0_chunk_rows(int D);
 void launch_l0_weight_image(const float *w, float *wt, int H, int D, int j_pad, int h_ld, hipStream_t s);
 
-// Frame tile (128/160/192) the int8 GEMM should use for `n` frames of a layer
+// Frame tile (32/64/128/160/256/320) the int8 GEMM should use for `n` frames of a layer
 // with rows_pad padded nodes; n_pad = n rounded up to it.
 int qgemm_frame_tile(int rows_pad, int n);
 int qgemm_debug_flags();
@@ -53,7 +53,7 @@ struct QGemmParams {
   const uint8_t *lut2;    // [kLut2Size] half-step table (fast epilogue)
   int rows, rows_pad, K, n, n_pad;
   int ldw, lda;           // row strides (bytes) of w and a: K plus the anti-channel-conflict skew
-  int frame_tile;         // 128 / 160 / 192 / 256 / 320, n_pad is a multiple of it
+  int frame_tile;         // 32 / 64 / 128 / 160 / 256 / 320, n_pad is a multiple of it
   int debug;              // timing experiments only (FDNN_GEMM_DEBUG): 1 no staging, 2 no MFMA, 4 no LDS reads
   float coef, rcp_coef;
   int fastdiv;
