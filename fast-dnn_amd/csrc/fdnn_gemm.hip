@@ -651,8 +651,12 @@ void launch_qgemm(const QGemmParams &p, hipStream_t s) {
     // a CU of its own anyway (small batches: one latency-bound k-loop per launch) a 6-stage
     // ring hides twice the load latency per step
     case 128:
-      if (static_cast<long>(p.rows_pad / G_BM) * (p.n_pad / 128) <= 256 && !p.tap_acc)
-        launch_cfg<4, 1, 64, 6, OUTPUT>(p, s);
+      if (static_cast<long>(p.rows_pad / G_BM) * (p.n_pad / 128) <= 256 && !p.tap_acc) {
+        if (small_bk == 128)
+          launch_cfg<4, 1, 128, 3, OUTPUT>(p, s);
+        else
+          launch_cfg<4, 1, 64, 6, OUTPUT>(p, s);
+      }
       else
         launch_cfg<4, 1, 64, 3, OUTPUT>(p, s);
       break;
