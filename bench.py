@@ -13,7 +13,7 @@ collective in the timed region (frames are independent: weak scaling).
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (contract in the task statement) including
-`roofline` for the dominant kernel (the int8 hidden-layer GEMM, measured with
+`roofline` for the dominant kernel class (the int8 hidden-layer GEMM, measured with
 HIP events on its launch stream in a second pass over the same K steps) and
 `cpu_baseline` (the SSE4.1 oracle port timed on this host, N=1 only).
 """
@@ -210,6 +210,19 @@ def main() -> None:
                 "avg_launch_ms": round(hid_ms, 4), "launches": hid["launches"],
             },
             "kernel_ms_per_step": kernels_ms,
+            # the other two bounds of the step, same live HIP-event times: layer 0 against the packed
+            # fp32 vector rate WITHOUT fma (multiply and add round separately in the canonical
+            # numerics: 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz), the soft-max scale against HBM
+            "roofline_other": [
+                {"kernel": "layer 0 (l0_image_kernel + l0_chain_kernel; --l0-fma: l0_mfma_kernel on the fp32 MFMA, 157.3 peak)",
+                 "bound": "mfma" if args.l0_fma else "valu",
+                 "achieved": round(2 * 432 * 2048 * n / (prof["l0"]["ms"] / args.steps * 1e-3) / 1e12, 1),
+                 "peak": 157.3 if args.l0_fma else 78.6, "unit": "TFLOP/s",
+                 "frac": round(2 * 432 * 2048 * n / (prof["l0"]["ms"] / args.steps * 1e-3) / 1e12 / (157.3 if args.l0_fma else 78.6), 4)},
+                {"kernel": "normalize_kernel (soft-max scale: read + write [n][8000] fp32)", "bound": "hbm",
+                 "achieved": round(2 * 8000 * 4 * n / (prof["normalize"]["ms"] / args.steps * 1e-3) / 1e9, 1), "peak": 8000.0,
+                 "unit": "GB/s", "frac": round(2 * 8000 * 4 * n / (prof["normalize"]["ms"] / args.steps * 1e-3) / 1e9 / 8000.0, 4)},
+            ],
             "other_layer0_flavour": None if alt is None else {
                 "layer0_numerics": "unfused (canonical)" if args.l0_fma else "fused (reference built -march=native), fp32 MFMA",
                 "frames_per_s": round(alt, 1)},
