@@ -467,3 +467,28 @@ def test_device_pointer_lazy_api(mid_model_path, x16):
     assert np.abs(dense.cpu().numpy() - dnn.calculate(x16)).max() == 0
     ctx.delete()
     dnn.delete()
+
+
+def test_blob_export_import_round_trip(mid_model_path, x16):
+    """What ranks 1..N-1 of the multi-GPU bench do (fast-dnn_amd/dist.py:load_replicated): a model
+    rebuilt from the exported device blob -- including the layer-0 weight image built at import --
+    scores bit-identically to the one loaded from the file, in both layer-0 flavours and kernels."""
+    import torch
+
+    a = api.QuantizedDnn.loadFromFile(mid_model_path)
+    nbytes = a.blobSize()
+    blob = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+    a.exportBlob(blob.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    b = api.QuantizedDnn.fromDeviceBlob(blob.data_ptr(), nbytes, 0)
+    del blob  # the import copies
+    x = F.synth_features(300, seed=123)
+    for fma in (False, True):
+        for kind in (0, 1, 2):
+            for d in (a, b):
+                d.setInputLayerFma(fma)
+                d.setInputLayerKernel(kind)
+            assert np.array_equal(a.calculate(x), b.calculate(x)), (fma, kind)
+    assert (b.inputDimension(), b.outputDimension(), b.layerCount()) == (a.inputDimension(), a.outputDimension(), a.layerCount())
+    b.delete()
+    a.delete()
