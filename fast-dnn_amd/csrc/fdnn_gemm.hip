@@ -633,8 +633,9 @@ void launch_qgemm(const QGemmParams &p, hipStream_t s) {
   switch (p.frame_tile) {
     // few frames: 32- / 64-frame tiles put four / two times as many workgroups on the chip; 128-byte
     // k-steps (3-stage ring) halve the barriers of the latency-bound loop: 16.6 vs 21 us per
-    // 2048 x 2048 layer.  What bounds these shapes is the weight tile's L2 -> LDS traffic (a
-    // 256-node tile pulls 512 KB per workgroup at ~33 B/clk/CU), not the matrix pipe.
+    // 2048 x 2048 layer.  What is left at this size is mostly the launch itself: a 128-node tile
+    // (half the operand traffic per workgroup) and whole-step fragment prefetch, both tried, left
+    // the 16.6 us untouched.
     case 32:
       if (small_bk == 128)
         launch_cfg<1, 1, 128, 3, OUTPUT>(p, s);
