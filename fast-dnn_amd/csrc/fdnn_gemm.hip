@@ -44,6 +44,7 @@
 #define FDNN_GEMM_DEBUG 0
 #endif
 
+
 namespace fdnn {
 namespace {
 
@@ -500,7 +501,12 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #if FDNN_GEMM_DEBUG & 16  // ablation: no output stores
             if (v.x == 1234.5f && ff < p.n && ncol0 + col < p.rows) *reinterpret_cast<float4 *>(op) = v;
 #else
-            if (ff < p.n && ncol0 + col < p.rows) *reinterpret_cast<float4 *>(op) = v;
+            if (ff < p.n && ncol0 + col < p.rows) {
+              if (FDNN_WT & 2)
+                store_wt(op, v4f_t{v.x, v.y, v.z, v.w});
+              else
+                *reinterpret_cast<float4 *>(op) = v;
+            }
 #endif
           } else if (ff < p.n) {
             const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -569,7 +575,13 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #else
       if (m0 + ch * 16 < p.rows)  // rows is a multiple of 16
 #endif
-        *reinterpret_cast<uint4 *>(p.act_out + static_cast<size_t>(f0 + row) * p.act_ld + m0 + ch * 16) = v;
+      {
+        int8_t *dst = p.act_out + static_cast<size_t>(f0 + row) * p.act_ld + m0 + ch * 16;
+        if (FDNN_WT & 1)
+          store_wt(dst, v4i{static_cast<int>(v.x), static_cast<int>(v.y), static_cast<int>(v.z), static_cast<int>(v.w)});
+        else
+          *reinterpret_cast<uint4 *>(dst) = v;
+      }
     }
   }
   if (OUTPUT) {

@@ -36,7 +36,10 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float *out, float 
       v.y = v.y / total;
       v.z = v.z / total;
       v.w = v.w / total;
-      d4[i] = v;
+      if (FDNN_WT & 32)
+        store_wt(d4 + i, v4f_t{v.x, v.y, v.z, v.w});
+      else
+        d4[i] = v;
     }
   } else {
     for (int i = tid; i < rows; i += 256) drow[i] = row[i] / total;

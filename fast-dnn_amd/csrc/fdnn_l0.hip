@@ -360,7 +360,11 @@ __global__ __launch_bounds__(256, 2) void l0_chain_kernel(L0Params p) {
         for (int a = 0; a < 8; ++a)
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
-            park[(a * 4 + b) * 256] = held[a][b] + acc[a][b];
+            const v2f t = held[a][b] + acc[a][b];
+            if (FDNN_WT & 4)  // read back from L2 either way; written through, it is not dirty when the kernel ends
+              store_wt(park + (a * 4 + b) * 256, v2f_t{t.x, t.y});
+            else
+              park[(a * 4 + b) * 256] = t;
             acc[a][b] = v2f{0.0f, 0.0f};
           }
       }
@@ -395,7 +399,10 @@ __global__ __launch_bounds__(256, 2) void l0_chain_kernel(L0Params p) {
           packed |= static_cast<uint32_t>(lut[lut_index(lin)]) << (8 * e);
         }
         // act_ld == h_ld: the pad nodes of the last tile land in the row's pad columns
-        *reinterpret_cast<uint32_t *>(p.act_out + static_cast<size_t>(f) * p.act_ld + n0 + grp * 64 + tx * 4) = packed;
+        if (FDNN_WT & 8)
+          store_wt(p.act_out + static_cast<size_t>(f) * p.act_ld + n0 + grp * 64 + tx * 4, packed);
+        else
+          *reinterpret_cast<uint32_t *>(p.act_out + static_cast<size_t>(f) * p.act_ld + n0 + grp * 64 + tx * 4) = packed;
       }
     }
   }
@@ -436,7 +443,10 @@ __global__ __launch_bounds__(256) void l0_image_kernel(const float *src, const f
     const int kl = hi + 16 * i, c = ((kl & 3) + 2) & 3, j = (k0 >> 2) + (kl >> 2);  // planes in pass order: chains 2, 3, 0, 1
     if (j >= j_pad) continue;
     const float4 v = make_float4(t[lo * 4 + 0][kl], t[lo * 4 + 1][kl], t[lo * 4 + 2][kl], t[lo * 4 + 3][kl]);
-    *reinterpret_cast<float4 *>(dst + (static_cast<size_t>(c) * j_pad + j) * ld + col0 + lo * 4) = v;
+    if (FDNN_WT & 16)
+      store_wt(dst + (static_cast<size_t>(c) * j_pad + j) * ld + col0 + lo * 4, v4f_t{v.x, v.y, v.z, v.w});
+    else
+      *reinterpret_cast<float4 *>(dst + (static_cast<size_t>(c) * j_pad + j) * ld + col0 + lo * 4) = v;
   }
 }
 
