@@ -32,6 +32,8 @@
 // per-lane GLOBAL address while the LDS destination stays lane-linear, and again
 // on the ds_read_b128 fragment reads, so every 16-lane read group hits 16
 // distinct 16-byte slots (conflict free; SQ_LDS_BANK_CONFLICT ~ 0).
+#include <atomic>
+
 #include "fdnn_device.hpp"
 #include "fdnn_kernels.hpp"
 
@@ -617,12 +619,16 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
   auto k_prod = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST>;
   auto k_tap = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, true, FAST>;
   auto k_plain = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT>;  // hidden layers: same as k_prod
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute is per device: a process may hold models on several GPUs
+  static std::atomic<unsigned long long> attr_set{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long dev_bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_prod), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_tap), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-    attr_set = true;
+    attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
   if (p.tap_acc)
     hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);

@@ -19,6 +19,8 @@
 //                   which is bit-for-bit what one block of v_mfma_f32_32x32x1_2b_f32
 //                   computes, so the four chains become four accumulator blocks fed
 //                   k = c, c+4, c+8, ...  (validated bit-for-bit against the FMA build).
+#include <atomic>
+
 #include "fdnn_device.hpp"
 #include "fdnn_kernels.hpp"
 
@@ -611,11 +613,15 @@ void launch_mfma(const L0Params &p, hipStream_t s) {
   using Cfg = L0MfmaCfg<BK, WFR>;
   auto k_prod = l0_mfma_kernel<BK, WFR, false>;
   auto k_tap = l0_mfma_kernel<BK, WFR, true>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute is per device: a process may hold models on several GPUs
+  static std::atomic<unsigned long long> attr_set{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long dev_bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_prod), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_tap), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
-    attr_set = true;
+    attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
   dim3 grid(l0_grid((p.H + Cfg::TN - 1) / Cfg::TN, (p.n_rows + Cfg::TF - 1) / Cfg::TF));
   hipLaunchKernelGGL(p.tap_lin ? k_tap : k_prod, grid, dim3(Cfg::THREADS), Cfg::LDS, s, p);
