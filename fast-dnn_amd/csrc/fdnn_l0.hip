@@ -27,7 +27,7 @@
 namespace fdnn {
 namespace {
 
-// Workgroup b runs on XCD b % 8.  All node tiles of a frame tile go to ONE XCD (frame tile =
+// Workgroup b runs on XCD b % 8 (mostly: a locality hint only).  All node tiles of a frame tile go to ONE XCD (frame tile =
 // xcd + 8 * (slot / node_tiles)), so a frame tile's input rows are pulled into one L2 instead of
 // all eight (PMC: 150 MB of HBM+MALL reads per launch for a 17 MB input with the plain 2-D grid).
 __device__ __forceinline__ bool l0_tile_of_block(int node_tiles, int frame_tiles, int &bx, int &by) {
