@@ -42,6 +42,8 @@
 
 // Timing experiments only (never set in the shipped build): bit 0 = no staging
 // loads after the prologue, bit 1 = no MFMA, bit 2 = no LDS fragment reads.
+// 1024 = workgroups return at once (launch cost: 2.4 us per kernel in a stream of launches,
+// 6.4 us when every launch is bracketed by HIP events as in bench.py's per-kernel pass).
 #ifndef FDNN_GEMM_DEBUG
 #define FDNN_GEMM_DEBUG 0
 #endif
@@ -106,6 +108,9 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #define FDNN_TS(i) ts[i] = __builtin_readcyclecounter()
 #else
 #define FDNN_TS(i)
+#endif
+#if FDNN_GEMM_DEBUG & 1024  // launch-cost experiment: the workgroups do nothing at all
+  if (p.n >= 0) return;
 #endif
   const int tid = threadIdx.x;
   const int lane = tid & 63;
