@@ -94,7 +94,9 @@ __device__ __forceinline__ v4i read_frag(const char *tile, int row, int chunk) {
 // (every layer of a sane net); !FAST keeps the true divide for the rest.
 // PLAIN (output layer only): no mask, no taps, output width a multiple of 4 -- the dense
 // production call, without the per-group branches of the general epilogue.
-template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool TAP, bool FAST, bool PLAIN = false>
+// MASKED (with PLAIN): the same branch-free epilogue for the batched lazy call -- mask present,
+// no taps, output width a multiple of 4; the mask only selects z = 0 for inactive nodes.
+template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool TAP, bool FAST, bool PLAIN = false, bool MASKED = false>
 __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (buffer-resource builtins are device-only)
   using Cfg = GemmCfg<NF, WN, BK, STAGES>;
@@ -460,11 +462,38 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     constexpr int kOS = 64 + 4;  // floats per tile row
     float *wtile = reinterpret_cast<float *>(smem + 8192) + wave * (32 * kOS);
     const int ncol0 = m0 + 64 * wm;
+    // Lazy contract: this wave's 32 x 64 piece of the mask goes through LDS first (16 dwords per
+    // row are one 64-byte segment: 8 wave-loads of 4 segments each) -- reading it straight from
+    // global memory where it is needed is 8 loads of 64 different cache lines each per piece,
+    // and made the masked call 60 % slower than the dense one.
+    constexpr int kMS = 64 + 16;  // bytes per mask tile row
+    uint8_t *mtile = reinterpret_cast<uint8_t *>(smem + 8192 + NW * (32 * kOS * 4)) + wave * (32 * kMS);
+    static_assert(8192 + NW * (32 * kOS * 4) + NW * (32 * kMS) <= Cfg::FIX_OFF, "mask tiles must not reach the table/biases");
+    const bool mask_staged = MASKED || (!PLAIN && p.mask != nullptr && vec4);
+    uint32_t mreg[8];  // the next piece is fetched while the current one is being used
+    auto mask_fetch = [&](int ni) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int item = lane + 64 * j, row = item >> 4, c4 = (item & 15) * 4;
+        const int ff = fw0 + 32 * ni + row, node = ncol0 + c4;
+        mreg[j] = 0;
+        if (ff < p.n && node < p.rows) mreg[j] = *reinterpret_cast<const uint32_t *>(p.mask + static_cast<size_t>(ff) * p.rows + node);
+      }
+    };
+    if ((MASKED || !PLAIN) && mask_staged) mask_fetch(0);
     {
 #pragma unroll
       for (int ni = 0; ni < NF; ++ni) {
         const int f = fw0 + 32 * ni + frow;
         const bool live = f < p.n;
+        if ((MASKED || !PLAIN) && mask_staged) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int item = lane + 64 * j;
+            *reinterpret_cast<uint32_t *>(mtile + (item >> 4) * kMS + (item & 15) * 4) = mreg[j];
+          }
+          if (ni + 1 < NF) mask_fetch(ni + 1);
+        }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -473,7 +502,9 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
             const float4 b4 = *reinterpret_cast<const float4 *>(bias_s + (nb - m0));
             const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
             uint32_t mbits = 0x01010101u;
-            if (!PLAIN && p.mask && live && nb < p.rows) {
+            if ((MASKED || !PLAIN) && mask_staged) {
+              mbits = *reinterpret_cast<const uint32_t *>(mtile + frow * kMS + (nb - ncol0));
+            } else if (!PLAIN && p.mask && live && nb < p.rows) {
               const int8_t *mp = p.mask + static_cast<size_t>(f) * p.rows + nb;
               if (vec4) {
                 mbits = *reinterpret_cast<const uint32_t *>(mp);
@@ -491,7 +522,7 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
               const int av = acc[mi][ni][g * 4 + q];
               if (!PLAIN && TAP && live && nb + q < p.rows) p.tap_acc[static_cast<size_t>(f) * p.rows + nb + q] = av;
               float z = dequant<FAST>(av, p.coef, p.rcp_coef) + bj[q];  // sum/coef, then += bias (dnn.cc:311, :446)
-              if (!PLAIN && ((mbits >> (8 * q)) & 0xffu) == 0) z = 0.0f;
+              if ((MASKED || !PLAIN) && ((mbits >> (8 * q)) & 0xffu) == 0) z = 0.0f;
               if (!PLAIN && TAP && live && nb + q < p.rows) p.tap_logit[static_cast<size_t>(f) * p.rows + nb + q] = z;
               e[q] = (PLAIN ? in4 : (nb + q < p.rows)) ? __expf(z) : 0.0f;
               psum[ni] += e[q];
@@ -626,6 +657,7 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
   auto k_prod = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST>;
   auto k_tap = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, true, FAST>;
   auto k_plain = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT>;  // hidden layers: same as k_prod
+  auto k_masked = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT>;
   // the attribute is per device: a process may hold models on several GPUs
   static std::atomic<unsigned long long> attr_set{0};
   int dev = 0;
@@ -635,12 +667,15 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_prod), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_tap), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_masked), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
   if (p.tap_acc)
     hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else if (OUTPUT && p.mask == nullptr && (p.rows & 3) == 0)
     hipLaunchKernelGGL(k_plain, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+  else if (OUTPUT && p.mask != nullptr && (p.rows & 3) == 0)
+    hipLaunchKernelGGL(k_masked, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else
     hipLaunchKernelGGL(k_prod, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
 }

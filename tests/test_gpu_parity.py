@@ -492,3 +492,33 @@ def test_blob_export_import_round_trip(mid_model_path, x16):
     assert (b.inputDimension(), b.outputDimension(), b.layerCount()) == (a.inputDimension(), a.outputDimension(), a.layerCount())
     b.delete()
     a.delete()
+
+
+@pytest.mark.parametrize("out_dim", [37, 101, 1003])
+def test_output_widths_not_multiple_of_four(tmp_models, out_dim):
+    """The output layer is the one layer the reference never pads (FeedForwardNetwork.extend): real
+    pdf counts are arbitrary.  Such widths take the general epilogue (scalar mask reads, scalar
+    stores) instead of the branch-free dense / masked instances -- dense and lazy, batch and
+    single frame, against the oracle."""
+    import os
+
+    p = os.path.join(tmp_models, f"out{out_dim}.bin")
+    F.write_model_bin(p, F.synth_net([432, 128, 128, 128, out_dim], seed=80 + out_dim))
+    x = F.synth_features(77, seed=out_dim)
+    masks = F.generate_masks(77, out_dim, 0.4, 0.05, seed=out_dim + 1)
+    orc = Oracle(p)
+    want, wt = orc.calculate(x, taps=True)
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    t = dnn.forwardTaps(x)
+    assert (t["acc_out"] == wt["acc_out"]).all()
+    assert np.abs(t["probs"] - want).max() <= TIGHT
+    assert np.array_equal(dnn.calculate(x), t["probs"])
+    ctx = dnn.getNewLazyContext(77)
+    ctx.calculateUntilOutput(x)
+    lazy_want = orc.lazy(x, masks)
+    got = ctx.calculateForOutputNodesBatch(masks)
+    assert np.abs(got - lazy_want).max() <= TIGHT
+    ctx.currentVectorIndex = 5  # the per-frame call walks the context frame by frame (LazyContext.java)
+    assert np.array_equal(ctx.calculateForOutputNodes(masks[5]), got[5])
+    ctx.delete()
+    dnn.delete()
