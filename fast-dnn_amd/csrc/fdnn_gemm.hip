@@ -92,7 +92,7 @@ __device__ __forceinline__ v4i read_frag(const char *tile, int row, int chunk) {
 
 // FAST: the layer's 3-op division was validated against IEEE division at load
 // (every layer of a sane net); !FAST keeps the true divide for the rest.
-// PLAIN (output layer only): no mask, no taps, output width a multiple of 4 -- the dense
+// PLAIN (output layer only): no mask, no taps (any output width; a multiple of 4 is a little cheaper) -- the dense
 // production call, without the per-group branches of the general epilogue.
 // MASKED (with PLAIN): the same branch-free epilogue for the batched lazy call -- mask present,
 // no taps, output width a multiple of 4; the mask only selects z = 0 for inactive nodes.
@@ -469,6 +469,7 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     constexpr int kMS = 64 + 16;  // bytes per mask tile row
     uint8_t *mtile = reinterpret_cast<uint8_t *>(smem + 8192 + NW * (32 * kOS * 4)) + wave * (32 * kMS);
     static_assert(8192 + NW * (32 * kOS * 4) + NW * (32 * kMS) <= Cfg::FIX_OFF, "mask tiles must not reach the table/biases");
+    const bool wt_rows = (p.rows & 31) == 0;
     const bool mask_staged = MASKED || (!PLAIN && p.mask != nullptr && vec4);
     uint32_t mreg[8];  // the next piece is fetched while the current one is being used
     auto mask_fetch = [&](int ni) {
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
               float z = dequant<FAST>(av, p.coef, p.rcp_coef) + bj[q];  // sum/coef, then += bias (dnn.cc:311, :446)
               if ((MASKED || !PLAIN) && ((mbits >> (8 * q)) & 0xffu) == 0) z = 0.0f;
               if (!PLAIN && TAP && live && nb + q < p.rows) p.tap_logit[static_cast<size_t>(f) * p.rows + nb + q] = z;
-              e[q] = (PLAIN ? in4 : (nb + q < p.rows)) ? __expf(z) : 0.0f;
+              e[q] = ((PLAIN && vec4) ? in4 : (nb + q < p.rows)) ? __expf(z) : 0.0f;
               psum[ni] += e[q];
             }
             *reinterpret_cast<float4 *>(wtile + frow * kOS + (nb - ncol0)) = make_float4(e[0], e[1], e[2], e[3]);
@@ -537,15 +538,22 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
           const float4 v = *reinterpret_cast<const float4 *>(wtile + row * kOS + col);
           const int ff = fw0 + 32 * ni + row;
           float *op = p.out + static_cast<size_t>(ff) * p.rows + ncol0 + col;
+          // whole groups of four as one store, whatever the output width: a row start off the
+          // 16-byte grid (rows % 4 != 0) is still 4-byte aligned, which is all global_store_dwordx4 needs
           if (PLAIN || vec4) {
 #if FDNN_GEMM_DEBUG & 16  // ablation: no output stores
             if (v.x == 1234.5f && ff < p.n && ncol0 + col < p.rows) *reinterpret_cast<float4 *>(op) = v;
 #else
-            if (ff < p.n && ncol0 + col < p.rows) {
-              if (FDNN_WT & 2)
+            if (ff < p.n && ncol0 + col + 4 <= p.rows) {
+              typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+              if ((FDNN_WT & 2) && wt_rows)  // rows of whole cache lines only: see normalize_kernel
                 store_wt(op, v4f_t{v.x, v.y, v.z, v.w});
               else
-                *reinterpret_cast<float4 *>(op) = v;
+                *reinterpret_cast<v4f_a4 *>(op) = v4f_a4{v.x, v.y, v.z, v.w};
+            } else if (PLAIN && !vec4 && ff < p.n) {  // the last, partial group of the row
+              const float vv[4] = {v.x, v.y, v.z, v.w};
+              for (int q = 0; q < 4; ++q)
+                if (ncol0 + col + q < p.rows) op[q] = vv[q];
             }
 #endif
           } else if (ff < p.n) {
@@ -672,7 +680,7 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
   }
   if (p.tap_acc)
     hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
-  else if (OUTPUT && p.mask == nullptr && (p.rows & 3) == 0)
+  else if (OUTPUT && p.mask == nullptr)
     hipLaunchKernelGGL(k_plain, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else if (OUTPUT && p.mask != nullptr && (p.rows & 3) == 0)
     hipLaunchKernelGGL(k_masked, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);

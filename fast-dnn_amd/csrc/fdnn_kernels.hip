@@ -27,20 +27,34 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float *out, float 
   const float total = (red[0] + red[1]) + (red[2] + red[3]);
   const float *row = out + static_cast<size_t>(f) * rows;
   float *drow = dst + static_cast<size_t>(f) * rows;
-  if ((rows & 3) == 0) {
-    const float4 *r4 = reinterpret_cast<const float4 *>(row);
-    float4 *d4 = reinterpret_cast<float4 *>(drow);
-    for (int i = tid; i < rows / 4; i += 256) {
+  // Rows of any width (pdf counts are arbitrary): when rows % 4 != 0 a row starts off the 16-byte
+  // grid, so up to three head elements are peeled to get there and the body goes as aligned
+  // dwordx4 accesses (misaligned dwordx4 accesses work but ran 0.188 ms for an 8001-wide layer,
+  // the plain scalar loop 0.153, this 0.108).  Source and destination must share the offset --
+  // in place they do; the one-frame lazy call's pinned destination falls back to scalars.
+  // write-through stores only when rows are whole cache lines: written through, a line shared by
+  // two rows (two workgroups) becomes two partial-line writes to memory (8016-wide layer: 0.187 ms
+  // against 0.118 with plain stores; 8000-wide: 0.108 against 0.112)
+  const bool wt_rows = (rows & 31) == 0;
+  const int head = static_cast<int>((4 - ((reinterpret_cast<uintptr_t>(row) >> 2) & 3)) & 3);
+  const bool same = ((reinterpret_cast<uintptr_t>(row) ^ reinterpret_cast<uintptr_t>(drow)) & 15) == 0;
+  if (same && rows >= head) {
+    const float4 *r4 = reinterpret_cast<const float4 *>(row + head);
+    float4 *d4 = reinterpret_cast<float4 *>(drow + head);
+    const int groups = (rows - head) >> 2, tail0 = head + 4 * groups;
+    for (int i = tid; i < groups; i += 256) {
       float4 v = r4[i];
       v.x = v.x / total;
       v.y = v.y / total;
       v.z = v.z / total;
       v.w = v.w / total;
-      if (FDNN_WT & 32)
+      if ((FDNN_WT & 32) && wt_rows)
         store_wt(d4 + i, v4f_t{v.x, v.y, v.z, v.w});
       else
         d4[i] = v;
     }
+    if (tid < head) drow[tid] = row[tid] / total;
+    if (tid >= 64 && tid - 64 < rows - tail0) drow[tail0 + tid - 64] = row[tail0 + tid - 64] / total;
   } else {
     for (int i = tid; i < rows; i += 256) drow[i] = row[i] / total;
   }
