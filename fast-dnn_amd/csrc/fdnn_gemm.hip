@@ -92,11 +92,13 @@ __device__ __forceinline__ v4i read_frag(const char *tile, int row, int chunk) {
 
 // FAST: the layer's 3-op division was validated against IEEE division at load
 // (every layer of a sane net); !FAST keeps the true divide for the rest.
-// PLAIN (output layer only): no mask, no taps (any output width; a multiple of 4 is a little cheaper) -- the dense
+// PLAIN (output layer only): no mask, no taps, rows of whole cache lines (width % 32 == 0) -- the dense
 // production call, without the per-group branches of the general epilogue.
 // MASKED (with PLAIN): the same branch-free epilogue for the batched lazy call -- mask present,
 // no taps, output width a multiple of 4; the mask only selects z = 0 for inactive nodes.
-template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool TAP, bool FAST, bool PLAIN = false, bool MASKED = false>
+// ANYW (with PLAIN): the dense call for every other output width (pdf counts are arbitrary):
+// per-element range test, 4-byte-aligned dwordx4 stores, scalar stores for a row's last group.
+template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool TAP, bool FAST, bool PLAIN = false, bool MASKED = false, bool ANYW = false>
 __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (buffer-resource builtins are device-only)
   using Cfg = GemmCfg<NF, WN, BK, STAGES>;
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
               float z = dequant<FAST>(av, p.coef, p.rcp_coef) + bj[q];  // sum/coef, then += bias (dnn.cc:311, :446)
               if ((MASKED || !PLAIN) && ((mbits >> (8 * q)) & 0xffu) == 0) z = 0.0f;
               if (!PLAIN && TAP && live && nb + q < p.rows) p.tap_logit[static_cast<size_t>(f) * p.rows + nb + q] = z;
-              e[q] = ((PLAIN && vec4) ? in4 : (nb + q < p.rows)) ? __expf(z) : 0.0f;
+              e[q] = ((PLAIN && !ANYW) ? in4 : (nb + q < p.rows)) ? __expf(z) : 0.0f;
               psum[ni] += e[q];
             }
             *reinterpret_cast<float4 *>(wtile + frow * kOS + (nb - ncol0)) = make_float4(e[0], e[1], e[2], e[3]);
@@ -546,11 +548,13 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #else
             if (ff < p.n && ncol0 + col + 4 <= p.rows) {
               typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
-              if ((FDNN_WT & 2) && wt_rows)  // rows of whole cache lines only: see normalize_kernel
+              // write-through for rows of whole cache lines only (see normalize_kernel): the PLAIN
+              // instance is launched for exactly those, the others test
+              if ((FDNN_WT & 2) && !ANYW && ((PLAIN && !MASKED) || wt_rows))
                 store_wt(op, v4f_t{v.x, v.y, v.z, v.w});
               else
                 *reinterpret_cast<v4f_a4 *>(op) = v4f_a4{v.x, v.y, v.z, v.w};
-            } else if (PLAIN && !vec4 && ff < p.n) {  // the last, partial group of the row
+            } else if (ANYW && ff < p.n) {  // the last, partial group of the row
               const float vv[4] = {v.x, v.y, v.z, v.w};
               for (int q = 0; q < 4; ++q)
                 if (ncol0 + col + q < p.rows) op[q] = vv[q];
@@ -666,6 +670,7 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
   auto k_tap = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, true, FAST>;
   auto k_plain = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT>;  // hidden layers: same as k_prod
   auto k_masked = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT>;
+  auto k_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, false, OUTPUT>;
   // the attribute is per device: a process may hold models on several GPUs
   static std::atomic<unsigned long long> attr_set{0};
   int dev = 0;
@@ -676,12 +681,15 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_tap), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_masked), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_anyw), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
   if (p.tap_acc)
     hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
-  else if (OUTPUT && p.mask == nullptr)
+  else if (OUTPUT && p.mask == nullptr && (p.rows & 31) == 0)
     hipLaunchKernelGGL(k_plain, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+  else if (OUTPUT && p.mask == nullptr)
+    hipLaunchKernelGGL(k_anyw, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else if (OUTPUT && p.mask != nullptr && (p.rows & 3) == 0)
     hipLaunchKernelGGL(k_masked, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else
