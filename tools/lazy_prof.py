@@ -3,15 +3,17 @@ import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 from fast_dnn_amd import api, formats as F
-p = "/tmp/fdnn_net_seed1_gauss.bin"
-F.ensure_model_file(p, F.NET_TOPOLOGY, seed=1, mode="gauss")
+O = int(os.environ.get("OUT_WIDTH", "8000"))
+p = f"/tmp/fdnn_out{O}.bin"
+if not os.path.exists(p):
+    F.write_model_bin(p, F.synth_net([432] + [2048] * 7 + [O], seed=1))
 dnn = api.QuantizedDnn.loadFromFile(p)
 n = 10000
 x = F.synth_features(n, 432, seed=5)
 for density in (0.4, 1.0):
-    masks = F.generate_masks(n, 8000, density, 0.03, seed=11) if density < 1 else np.ones((n, 8000), dtype=np.int8)
+    masks = F.generate_masks(n, O, density, 0.03, seed=11) if density < 1 else np.ones((n, O), dtype=np.int8)
     ctx = dnn.getNewLazyContext(n)
-    xd = torch.from_numpy(x).cuda(); md = torch.from_numpy(masks).cuda(); od = torch.empty((n, 8000), dtype=torch.float32, device="cuda")
+    xd = torch.from_numpy(x).cuda(); md = torch.from_numpy(masks).cuda(); od = torch.empty((n, O), dtype=torch.float32, device="cuda")
     def step():
         ctx.calculateUntilOutputDevice(xd.data_ptr(), 0)
         ctx.calculateForOutputNodesBatchDevice(md.data_ptr(), od.data_ptr(), 0, n, 0)
@@ -21,5 +23,5 @@ for density in (0.4, 1.0):
     for _ in range(50): step()
     torch.cuda.synchronize()
     prof = dnn.profileEnd()
-    print("mask density", density, {k: round(v["ms"] / 50, 4) for k, v in prof.items()})
+    print("mask density", density, "width", O, {k: round(v["ms"] / 50, 4) for k, v in prof.items()})
     ctx.delete()
