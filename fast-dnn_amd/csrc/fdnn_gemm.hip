@@ -95,7 +95,7 @@ __device__ __forceinline__ v4i read_frag(const char *tile, int row, int chunk) {
 // PLAIN (output layer only): no mask, no taps, rows of whole cache lines (width % 32 == 0) -- the dense
 // production call, without the per-group branches of the general epilogue.
 // MASKED (with PLAIN): the same branch-free epilogue for the batched lazy call -- mask present,
-// no taps, output width a multiple of 4; the mask only selects z = 0 for inactive nodes.
+// no taps; the mask only selects z = 0 for inactive nodes (with ANYW for widths % 4 != 0).
 // ANYW (with PLAIN): the dense call for every other output width (pdf counts are arbitrary):
 // per-element range test, 4-byte-aligned dwordx4 stores, scalar stores for a row's last group.
 template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool TAP, bool FAST, bool PLAIN = false, bool MASKED = false, bool ANYW = false>
@@ -480,7 +480,16 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
         const int item = lane + 64 * j, row = item >> 4, c4 = (item & 15) * 4;
         const int ff = fw0 + 32 * ni + row, node = ncol0 + c4;
         mreg[j] = 0;
-        if (ff < p.n && node < p.rows) mreg[j] = *reinterpret_cast<const uint32_t *>(p.mask + static_cast<size_t>(ff) * p.rows + node);
+        if (ff < p.n && node < p.rows) {
+          const int8_t *mp = p.mask + static_cast<size_t>(ff) * p.rows + node;
+          if (!ANYW) {
+            mreg[j] = *reinterpret_cast<const uint32_t *>(mp);
+          } else {  // rows % 4 != 0: the piece starts at any byte, and the last row must not be overread
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (node + q < p.rows) mreg[j] |= static_cast<uint32_t>(static_cast<uint8_t>(mp[q])) << (8 * q);
+          }
+        }
       }
     };
     if ((MASKED || !PLAIN) && mask_staged) mask_fetch(0);
@@ -671,6 +680,7 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
   auto k_plain = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT>;  // hidden layers: same as k_prod
   auto k_masked = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT>;
   auto k_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, false, OUTPUT>;
+  auto k_masked_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT, OUTPUT>;
   // the attribute is per device: a process may hold models on several GPUs
   static std::atomic<unsigned long long> attr_set{0};
   int dev = 0;
@@ -682,6 +692,7 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_plain), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_masked), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_anyw), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_masked_anyw), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
   if (p.tap_acc)
@@ -692,6 +703,8 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     hipLaunchKernelGGL(k_anyw, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else if (OUTPUT && p.mask != nullptr && (p.rows & 3) == 0)
     hipLaunchKernelGGL(k_masked, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+  else if (OUTPUT && p.mask != nullptr)  // 8001 nodes: 0.33 ms against 0.41 through the general epilogue
+    hipLaunchKernelGGL(k_masked_anyw, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else
     hipLaunchKernelGGL(k_prod, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
 }
