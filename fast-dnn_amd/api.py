@@ -187,7 +187,11 @@ class LazyContext:
     # batched form of the same contract
     def calculateForOutputNodesBatch(self, masks, first: int = 0) -> np.ndarray:
         masks = np.ascontiguousarray(masks, dtype=np.int8)
+        if masks.ndim != 2 or masks.shape[1] != self.dnn.outputDimension():  # the C side reads count x output_dim bytes
+            raise ValueError(f"masks must be count x {self.dnn.outputDimension()}, got {masks.shape}")
         count = masks.shape[0]
+        if first < 0 or first + count > self.inputVectorCount:
+            raise ValueError(f"frames [{first}, {first + count}) outside the context's {self.inputVectorCount} frames")
         out = np.empty((count, self.dnn.outputDimension()), dtype=np.float32)
         _check(lib().fdnn_ctx_lazy_output_batch(self.handle, first, count, masks.ctypes.data_as(_c_i8p),
                                                 out.ctypes.data_as(_c_f32p)))

@@ -175,11 +175,6 @@ int pack(const std::vector<RawLayer> &layers, const std::vector<float> &shift, c
       }
       t.wsum[size_t(r)] = 128 * s;
       (void)first;
-      if (t.ent.size() > size_t(kMaxFixPerLayer)) {
-        *msg = "layer " + std::to_string(qi + 1) + ": more than " + std::to_string(kMaxFixPerLayer) +
-               " weight pairs whose pmaddubsw sum can saturate; the sparse correction path is not sized for that";
-        return FDNN_E_FORMAT;
-      }
       if ((r & 63) == 63) t.fix_grp[size_t(r) / 64 + 1] = int32_t(t.ent.size());
     }
     // close the ranges of a partial last group and of the padding groups
@@ -366,6 +361,46 @@ int adopt_blob(std::vector<uint8_t> &&bytes, HostModel *out, std::string *msg) {
       h.n_q > kMaxQLayers) {
     *msg = "not a fast-dnn weight blob (magic/version/size mismatch)";
     return FDNN_E_FORMAT;
+  }
+  // Everything below drives device buffer descriptors and the scalar walk of the fix lists: a
+  // truncated or foreign blob must be refused here, not read out of bounds on the GPU.
+  const uint64_t total = h.total_bytes;
+  auto inside = [&](uint64_t off, uint64_t len) { return off >= sizeof(BlobHeader) && off <= total && len <= total - off && off % 16 == 0; };
+  auto bad = [&](const std::string &what) {
+    *msg = "weight blob rejected: " + what;
+    return FDNN_E_FORMAT;
+  };
+  if (h.n_affine != h.n_q + 1 || h.in_dim <= 0 || h.in_dim % 4 || h.hidden <= 0 || h.hidden % 16 || h.out_dim <= 0 ||
+      h.in_dim > (1 << 20) || h.hidden > 32768)
+    return bad("inconsistent dimensions");
+  const uint64_t H = uint64_t(h.hidden), D = uint64_t(h.in_dim);
+  if (!inside(h.off_w0, 4 * H * D) || !inside(h.off_b0, 4 * H) || !inside(h.off_shift, 4 * D) || !inside(h.off_scale, 4 * D) ||
+      !inside(h.off_lut, uint64_t(kLutExt)) || !inside(h.off_lut2, uint64_t(kLut2Size)))
+    return bad("layer-0 / table sections outside the blob");
+  for (int qi = 0; qi < h.n_q; ++qi) {
+    const QLayerDesc &d = h.q[qi];
+    const std::string L = "int8 layer " + std::to_string(qi + 1) + ": ";
+    const bool last = qi == h.n_q - 1;
+    if (d.rows <= 0 || d.cols != h.hidden || d.rows != (last ? h.out_dim : h.hidden) || d.rows_pad < d.rows ||
+        d.rows_pad % kRowPad || d.rows_pad - d.rows >= kRowPad || d.cols_pad != int32_t(align_up(size_t(d.cols), kColPad)) + kRowSkew ||
+        d.n_fix < 0)
+      return bad(L + "inconsistent dimensions");
+    const uint64_t rp = uint64_t(d.rows_pad), groups = rp / 64 + 1;
+    if (!inside(d.off_w, rp * uint64_t(d.cols_pad)) || !inside(d.off_bias, 4 * rp) || !inside(d.off_wsum, 4 * rp) ||
+        !inside(d.off_fix_grp, 4 * groups) || !inside(d.off_fix_ent, sizeof(FixEntry) * (uint64_t(d.n_fix) + 1)))
+      return bad(L + "section outside the blob");
+    const int32_t *grp = reinterpret_cast<const int32_t *>(bytes.data() + d.off_fix_grp);
+    if (grp[0] != 0 || grp[groups - 1] != d.n_fix) return bad(L + "fix-up group table does not cover the entry list");
+    for (uint64_t gi = 0; gi + 1 < groups; ++gi)
+      if (grp[gi] > grp[gi + 1]) return bad(L + "fix-up group table not monotone");
+    const FixEntry *ent = reinterpret_cast<const FixEntry *>(bytes.data() + d.off_fix_ent);
+    for (uint64_t gi = 0; gi + 1 < groups; ++gi)
+      for (int32_t e = grp[gi]; e < grp[gi + 1]; ++e) {
+        // the GEMM derives an accumulator register from node - 64*group and reads LDS at column k
+        if (ent[e].node < int32_t(gi) * 64 || ent[e].node >= int32_t(gi + 1) * 64 || ent[e].node >= d.rows || (ent[e].k & 1) ||
+            int(ent[e].k) + 1 >= d.cols || (e > grp[gi] && ent[e].k < ent[e - 1].k))
+          return bad(L + "fix-up entry out of range or out of order");
+      }
   }
   out->hdr = h;
   out->blob = std::move(bytes);

@@ -26,7 +26,10 @@ constexpr uint32_t kBlobVersion = 6;
 constexpr int kRowPad = 256;        // int8 weight rows padded to the GEMM node tile
 constexpr int kColPad = 128;        // int8 weight columns (and activation rows) padded to the GEMM k-step
 constexpr int kRowSkew = 0;         // extra bytes on int8 row strides (0: measured slower with a 64-byte skew)
-constexpr int kMaxFixPerLayer = 1 << 20;  // saturating pairs one layer may carry (each costs a gather per frame tile)
+// No cap on the saturating pairs a layer may carry: the reference runs any weights, so does this
+// path (a layer of 2^24 x 2^15 / 2 pairs still indexes with int32).  Each listed pair costs a
+// gather per frame tile, so a net whose weights sit near +-127 everywhere runs correctly but at a
+// fraction of the MFMA rate.
 
 // One (node, adjacent weight pair) entry whose pmaddubsw pair sum can leave
 // int16 for some activation (dnn.cc:337-340): k is the even column.

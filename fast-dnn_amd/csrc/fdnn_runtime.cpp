@@ -69,7 +69,9 @@ struct fdnn_ctx {
   int cap = 0;            // frames the scratch was allocated for (padded)
   int act_ld = 0;
   hipStream_t stream = nullptr;   // own stream for the host-pointer entry points
-  hipEvent_t done = nullptr;      // last enqueued work (pool hand-over between streams)
+  hipEvent_t done = nullptr;      // last enqueued work (pool hand-over between streams, ctx_enter/ctx_leave)
+  hipStream_t done_stream = nullptr;  // the stream `done` was last recorded on
+  bool done_valid = false;
   float *d_x = nullptr;           // [n][D]
   float *d_xt = nullptr;          // [4][l0_j_pad][xt_ld] layer-0 frame image (shifted, scaled, chain-major)
   int xt_ld = 0;
@@ -444,8 +446,23 @@ int acquire_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
   return FDNN_OK;
 }
 
+// A context's scratch is touched from two kinds of streams: the caller's (the *_device entry
+// points) and the context's own (the host-pointer entry points; created non-blocking, so not even
+// the NULL stream orders it).  Every entry point therefore starts by making its stream wait for
+// the context's last enqueued work and ends by recording it: calculateUntilOutputDevice(stream)
+// followed by calculateForOutputNodes() or hiddenActivations() reads finished activations
+// without the caller synchronising anything.  On one stream both calls are no-ops for the device.
+hipError_t ctx_enter(fdnn_ctx *c, hipStream_t s) {
+  if (c->done_valid && c->done_stream == s) return hipSuccess;  // same stream: already in order
+  return hipStreamWaitEvent(s, c->done, 0);
+}
+void ctx_leave(fdnn_ctx *c, hipStream_t s) {
+  c->done_valid = hipEventRecord(c->done, s) == hipSuccess;
+  c->done_stream = s;
+}
+
 void release_ctx(fdnn_ctx *c, hipStream_t s) {
-  hipEventRecord(c->done, s);
+  ctx_leave(c, s);
   fdnn_model *m = c->m;
   fdnn_ctx *victim = nullptr;
   {
@@ -569,7 +586,11 @@ int fdnn_ctx_forward_hidden_device(fdnn_ctx *c, const float *d_x, void *stream) 
     return FDNN_OK;
   }
   DeviceGuard g(c->m->device);
-  return run_hidden(c, d_x, static_cast<hipStream_t>(stream), nullptr);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(ctx_enter(c, s));
+  int rc = run_hidden(c, d_x, s, nullptr);
+  ctx_leave(c, s);
+  return rc;
 }
 
 int fdnn_ctx_forward_hidden(fdnn_ctx *c, const float *x) {
@@ -580,8 +601,10 @@ int fdnn_ctx_forward_hidden(fdnn_ctx *c, const float *x) {
   }
   DeviceGuard g(c->m->device);
   const BlobHeader &h = c->m->hm.hdr;
+  HIP_TRY(ctx_enter(c, c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_x, x, sizeof(float) * size_t(c->n) * h.in_dim, hipMemcpyHostToDevice, c->stream));
   int rc = run_hidden(c, c->d_x, c->stream, nullptr);
+  ctx_leave(c, c->stream);
   if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return FDNN_OK;
@@ -591,7 +614,11 @@ int fdnn_ctx_lazy_output_batch_device(fdnn_ctx *c, int first, int count, const i
                                       void *stream) {
   if (!c || !d_out) return fail(FDNN_E_ARG, "null argument");
   DeviceGuard g(c->m->device);
-  return run_output(c, first, count, d_masks, d_out, static_cast<hipStream_t>(stream), nullptr);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(ctx_enter(c, s));
+  int rc = run_output(c, first, count, d_masks, d_out, s, nullptr);
+  ctx_leave(c, s);
+  return rc;
 }
 
 int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *masks, float *out) {
@@ -602,6 +629,7 @@ int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *
   DeviceGuard g(c->m->device);
   const BlobHeader &h = c->m->hm.hdr;
   const size_t O = size_t(h.out_dim);
+  HIP_TRY(ctx_enter(c, c->stream));
   if (count <= kPinFrames) {  // the per-frame protocol: no copy commands (see fdnn_ctx)
     std::memcpy(c->h_mask_pin, masks, size_t(count) * O);
     int rc = FDNN_OK;
@@ -634,6 +662,7 @@ int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *
     } else {
       rc = run_output(c, first, count, c->d_mask_pin, c->d_out, c->stream, nullptr, c->d_out_pin);
     }
+    ctx_leave(c, c->stream);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::memcpy(out, c->h_out_pin, sizeof(float) * size_t(count) * O);
@@ -641,6 +670,7 @@ int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *
   }
   HIP_TRY(hipMemcpyAsync(c->d_mask, masks, size_t(count) * O, hipMemcpyHostToDevice, c->stream));
   int rc = run_output(c, first, count, c->d_mask, c->d_out, c->stream, nullptr);
+  ctx_leave(c, c->stream);
   if (rc) return rc;
   return copy_out(out, c->d_out, sizeof(float) * size_t(count) * O, c->stream);
 }
@@ -652,14 +682,20 @@ int fdnn_ctx_lazy_output(fdnn_ctx *c, int frame, const int8_t *mask, float *out)
 int fdnn_ctx_output_device(fdnn_ctx *c, float *d_out, void *stream) {
   if (!c || !d_out) return fail(FDNN_E_ARG, "null argument");
   DeviceGuard g(c->m->device);
-  return run_output(c, 0, c->n, nullptr, d_out, static_cast<hipStream_t>(stream), nullptr);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(ctx_enter(c, s));
+  int rc = run_output(c, 0, c->n, nullptr, d_out, s, nullptr);
+  ctx_leave(c, s);
+  return rc;
 }
 
 int fdnn_ctx_output(fdnn_ctx *c, float *out) {
   if (!c || !out) return fail(FDNN_E_ARG, "null argument");
   if (c->n == 0) return FDNN_OK;
   DeviceGuard g(c->m->device);
+  HIP_TRY(ctx_enter(c, c->stream));
   int rc = run_output(c, 0, c->n, nullptr, c->d_out, c->stream, nullptr);
+  ctx_leave(c, c->stream);
   if (rc) return rc;
   return copy_out(out, c->d_out, sizeof(float) * size_t(c->n) * c->m->hm.hdr.out_dim, c->stream);
 }
@@ -671,8 +707,9 @@ int fdnn_ctx_read_hidden(fdnn_ctx *c, uint8_t *out) {
   DeviceGuard g(c->m->device);
   const int H = c->m->hm.hdr.hidden;
   std::vector<int8_t> tmp(size_t(c->n) * c->act_ld);
+  HIP_TRY(ctx_enter(c, c->stream));  // the hidden layers may have been enqueued on a caller's stream
+  HIP_TRY(hipMemcpyAsync(tmp.data(), c->d_act[c->last], tmp.size(), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipMemcpy(tmp.data(), c->d_act[c->last], tmp.size(), hipMemcpyDeviceToHost));
   for (int f = 0; f < c->n; ++f)
     for (int i = 0; i < H; ++i) out[size_t(f) * H + i] = uint8_t(tmp[size_t(f) * c->act_ld + i]) ^ 0x80;
   return FDNN_OK;
@@ -688,10 +725,13 @@ int fdnn_calculate_device(fdnn_model *m, const float *d_x, int n, float *d_out, 
   fdnn_ctx *c = nullptr;
   int rc = acquire_ctx(m, n, &c);
   if (rc) return rc;
-  HIP_TRY(hipStreamWaitEvent(s, c->done, 0));
-  rc = run_hidden(c, d_x, s, nullptr);
-  if (!rc) rc = run_output(c, 0, n, nullptr, d_out, s, nullptr);
-  release_ctx(c, s);
+  const hipError_t e = ctx_enter(c, s);
+  if (e == hipSuccess) {
+    rc = run_hidden(c, d_x, s, nullptr);
+    if (!rc) rc = run_output(c, 0, n, nullptr, d_out, s, nullptr);
+  }
+  release_ctx(c, s);  // also on the error paths: the context goes back to the pool
+  if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("fdnn_calculate_device: ") + hipGetErrorString(e));
   return rc;
 }
 

@@ -20,6 +20,14 @@
  *     at once (jni_dnn.cc:49-51 gives every call its own context; here calls
  *     draw a device context from a per-model pool).  A context handle is
  *     single-threaded, like the reference's LazyContext.
+ *   - stream ordering on a context: the *_device entry points enqueue on the
+ *     caller's stream and do not synchronize; the host-pointer entry points use
+ *     the context's own stream and return with their result complete.  Calls on
+ *     ONE context are ordered behind each other whatever streams they use (each
+ *     waits, on the device, for the context's previously enqueued work), so
+ *     forward_hidden_device(stream) followed by lazy_output() / read_hidden()
+ *     needs no synchronization by the caller.  Caller-owned buffers (d_x,
+ *     d_masks, d_out) are the caller's to order.
  *   - there is no CPU fallback: without a usable HIP device every entry point
  *     that computes returns FDNN_E_DEVICE.
  */

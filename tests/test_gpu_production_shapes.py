@@ -1,0 +1,187 @@
+"""Parity of the kernel instances production actually dispatches at BASELINE's full sizes.
+
+The small-batch tests of test_gpu_parity.py run the 32/64/128-frame 4-wave tiles.  A 10 000-frame
+batch of the 7x2048 -> 8000 net runs the 8-wave 256-node x 320-frame tile (rotated-barrier k-loop,
+16 k-steps, saturation walk, mask staged through LDS): these tests meet the oracle THERE --
+hundreds of frames sampled from every frame tile, integer state bit for bit -- plus the
+size-independent properties on every row (reference: dnn.cc:355-392, :402-454)."""
+import os
+
+import numpy as np
+import pytest
+
+from fast_dnn_amd import api, formats as F
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+TIGHT = 2e-6
+
+
+def sample_every_tile(n, tile, per_tile, seed):
+    """`per_tile` frame indices out of every `tile`-frame tile of [0, n): first and last row of the
+    tile (the wave / MFMA-block edges) and random rows in between."""
+    rng = np.random.default_rng(seed)
+    idx = []
+    for t0 in range(0, n, tile):
+        hi = min(t0 + tile, n)
+        pick = {t0, hi - 1}
+        while len(pick) < min(per_tile, hi - t0):
+            pick.add(int(rng.integers(t0, hi)))
+        idx.extend(sorted(pick))
+    return np.array(idx)
+
+
+def test_dense_10k_hidden_u8_bit_exact_on_sampled_frames(net_model_path):
+    """configs[2]: the last hidden layer's u8 activations (six 16-step rotated k-loops with the
+    saturation walk behind them) for 16 frames of each of the 32 frame tiles, bit for bit; the
+    soft-max rows of the same frames to 2e-6."""
+    n = 10000
+    x = F.synth_features(n, 432, seed=21)
+    idx = sample_every_tile(n, 320, 16, seed=1)
+    assert idx.size >= 512
+    orc = Oracle(net_model_path)
+    want, wt = orc.calculate(x[idx], taps=True)
+    assert wt["sat_events"] > 0  # the gauss net does saturate: the fix-up walk is exercised
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    ctx = dnn.getNewLazyContext(n)
+    ctx.calculateUntilOutput(x)
+    hid = ctx.hiddenActivations()
+    ctx.delete()
+    assert (hid[idx] == wt["u8_acts"][-1]).all()
+    p = dnn.calculate(x)
+    assert np.abs(p[idx] - want).max() <= TIGHT
+    assert np.abs(p.sum(1, dtype=np.float64) - 1).max() < 1e-4
+    dnn.delete()
+
+
+def test_lazy_10k_masked_kernel_at_production_shape(net_model_path):
+    """configs[3]: 10 000 frames, 40 % mask with 3 % churn (FuncTest.java:121-133) through the
+    device-pointer batched lazy call = qgemm_kernel<5,2,128,2,OUTPUT,..,PLAIN,MASKED>.  16 frames
+    of every 320-frame tile against LazyOutputActivations (dnn.cc:355-392); on every row:
+    sum == 1, masked-out nodes all equal 1/total (exp(0) terms, dnn.cc:366-369)."""
+    import torch
+
+    n, O = 10000, 8000
+    x = F.synth_features(n, 432, seed=51)
+    masks = F.generate_masks(n, O, 0.40, 0.03, seed=7)
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    ctx = dnn.getNewLazyContext(n)
+    xd = torch.from_numpy(x).cuda()
+    md = torch.from_numpy(masks).cuda()
+    od = torch.zeros((n, O), dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.calculateUntilOutputDevice(xd.data_ptr(), s)
+    ctx.calculateForOutputNodesBatchDevice(md.data_ptr(), od.data_ptr(), 0, n, s)
+    torch.cuda.synchronize()
+    # properties on all rows, on the device (320 MB)
+    assert float((od.sum(1, dtype=torch.float64) - 1).abs().max()) < 1e-4
+    off = md == 0
+    lo = torch.where(off, od, torch.full_like(od, float("inf"))).min(1).values
+    hi = torch.where(off, od, torch.full_like(od, float("-inf"))).max(1).values
+    assert bool((lo == hi).all()) and float(lo.min()) > 0   # one value per row for the masked-out nodes
+    idx = sample_every_tile(n, 320, 16, seed=2)
+    assert idx.size >= 512
+    got = od[torch.from_numpy(idx).cuda()].cpu().numpy()
+    want = Oracle(net_model_path).lazy(x[idx], masks[idx])
+    assert np.abs(got - want).max() <= TIGHT
+    # all-ones masks through the masked instance == the dense instance, bit for bit
+    md.fill_(1)
+    ctx.calculateForOutputNodesBatchDevice(md.data_ptr(), od.data_ptr(), 0, n, s)
+    dense = torch.empty_like(od)
+    dnn.calculate_device(xd.data_ptr(), n, dense.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert torch.equal(od, dense)
+    ctx.delete()
+    dnn.delete()
+
+
+@pytest.mark.parametrize("out_dim,n", [(1003, 12000), (1000, 20000), (1003, 20000)])
+def test_small_net_big_batch_masked_8_wave_tiles(tmp_models, out_dim, n):
+    """A net small enough for the oracle to score EVERY frame, with enough frames that
+    rows_pad/256 * ceil(n/128) > 256 picks the 8-wave 256/320-frame tiles: the MASKED (+ANYW for a
+    width that is not a multiple of four) epilogue with its LDS-staged mask, all frames.
+    12 000 frames -> 256-frame tiles, 20 000 -> 320-frame tiles (qgemm_frame_tile's cost model)."""
+    p = os.path.join(tmp_models, f"smallnet_out{out_dim}.bin")
+    F.write_model_bin(p, F.synth_net([432, 128, 128, 128, out_dim], seed=90 + out_dim))
+    x = F.synth_features(n, 432, seed=out_dim)
+    masks = F.generate_masks(n, out_dim, 0.40, 0.03, seed=out_dim + 3)
+    orc = Oracle(p)
+    want_lazy = orc.lazy(x, masks)
+    want_dense, wt = orc.calculate(x, taps=True)
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    ctx = dnn.getNewLazyContext(n)
+    ctx.calculateUntilOutput(x)
+    assert (ctx.hiddenActivations() == wt["u8_acts"][-1]).all()
+    got = ctx.calculateForOutputNodesBatch(masks)
+    assert np.abs(got - want_lazy).max() <= TIGHT
+    sub = ctx.calculateForOutputNodesBatch(masks[777:11000], first=777)  # unaligned first row, ragged last tile
+    assert np.array_equal(sub, got[777:11000])
+    ctx.delete()
+    assert np.abs(dnn.calculate(x) - want_dense).max() <= TIGHT
+    dnn.delete()
+
+
+def test_context_orders_device_and_host_entry_points(net_model_path):
+    """A context's *_device entries run on the caller's stream, its host-pointer entries on its
+    own non-blocking stream.  The library orders them (fdnn.h, "stream ordering on a context"):
+    hidden layers enqueued on a side stream -- behind a long kernel, so they are certainly not
+    finished when the next call is made -- followed at once by host-pointer reads."""
+    import torch
+
+    n = 2000
+    x = F.synth_features(n, 432, seed=61)
+    masks = F.generate_masks(8, 8000, 0.40, 0.03, seed=3)
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    ref = dnn.getNewLazyContext(n)
+    ref.calculateUntilOutput(x)
+    want_hidden = ref.hiddenActivations()
+    want_rows = np.stack([ref.calculateForOutputNodes(masks[i]) for i in range(8)])
+    ref.delete()
+    side = torch.cuda.Stream()
+    xd = torch.from_numpy(x).cuda()
+    big = torch.randn((8192, 8192), device="cuda")
+    torch.cuda.synchronize()
+    for trial in range(3):
+        ctx = dnn.getNewLazyContext(n)
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                big = (big @ big).clamp_(-1, 1)          # ~10 ms of work ahead of the hidden layers
+        ctx.calculateUntilOutputDevice(xd.data_ptr(), side.cuda_stream)
+        if trial == 0:
+            got = ctx.hiddenActivations()                 # host entry, context stream: no sync by the caller
+            assert (got == want_hidden).all()
+        rows = np.stack([ctx.calculateForOutputNodes(masks[i]) for i in range(8)])
+        assert (rows == want_rows).all()
+        # and back: host-pointer forward, then a device-pointer output on the side stream
+        ctx.calculateUntilOutput(x)
+        od = torch.zeros((8, 8000), dtype=torch.float32, device="cuda")
+        md = torch.from_numpy(masks).cuda()
+        ctx.calculateForOutputNodesBatchDevice(md.data_ptr(), od.data_ptr(), 0, 8, side.cuda_stream)
+        side.synchronize()
+        assert (od.cpu().numpy() == want_rows).all()
+        ctx.delete()
+    dnn.delete()
+
+
+def test_net_with_every_pair_saturating(tmp_models):
+    """Weights near +-127 everywhere: nearly every adjacent pair can leave int16, so the sparse
+    correction walks tens of thousands of entries per 64-node group and pmaddubsw really
+    saturates for most of them (dnn.cc:337-340).  Slow by design, bit-exact all the same."""
+    net = F.synth_net([432, 256, 256, 256, 300], seed=17)
+    rng = np.random.default_rng(5)
+    for L in net.layers[1:]:
+        L.weights[:] = rng.choice(np.array([-0.5, 0.5, 0.45, -0.48], np.float32), size=L.weights.shape)
+    p = os.path.join(tmp_models, "allsat_small.bin")
+    F.write_model_bin(p, net)
+    hm = api.HostModel(p)
+    assert hm.risky_pairs(1) > 256 * 128 // 3
+    x = F.synth_features(700, 432, seed=9)
+    want, wt = Oracle(p).calculate(x, taps=True)
+    assert wt["sat_events"] > 100000
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    t = dnn.forwardTaps(x)
+    assert (t["acc_hid"] == wt["acc_hid"]).all() and (t["acc_out"] == wt["acc_out"]).all()
+    assert (t["u8_acts"] == wt["u8_acts"]).all()
+    assert np.abs(t["probs"] - want).max() <= TIGHT
+    assert np.abs(dnn.calculate(x) - want).max() <= TIGHT
+    dnn.delete()

@@ -121,3 +121,45 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in txt.lower() or f == "__init__.py" and False, os.path.join(dirpath, f)
+
+
+def test_received_blob_is_bounds_checked(tiny_model_path):
+    """adopt_blob (what a rank does with the broadcast weights): every section offset, the padded
+    dimensions and the saturation fix-up lists are validated before they can drive device reads."""
+    import struct
+
+    blob = api.HostModel(tiny_model_path).blob()
+    assert api.host_blob_check(blob)["hidden_dim"] == 64
+    hdr_q0 = 96  # BlobHeader: 16 bytes magic/version/size, 8 ints/floats, 6 u64 offsets, then QLayerDesc q[]
+
+    def rejects(mutate):
+        b = blob.copy()
+        mutate(b)
+        with pytest.raises(api.FdnnError) as e:
+            api.host_blob_check(b)
+        assert e.value.code == api.FDNN_E_FORMAT
+
+    rejects(lambda b: b.__setitem__(slice(0, 4), np.frombuffer(b"XXXX", np.uint8)))           # magic
+    with pytest.raises(api.FdnnError):
+        api.host_blob_check(blob[:-256])                                                         # truncated
+    off_w0 = 16 + 8 * 4  # magic, version, total_bytes, 8 ints/floats
+    assert struct.unpack_from("<Q", blob, off_w0)[0] % 256 == 0 and struct.unpack_from("<Q", blob, off_w0)[0] < blob.size
+    rejects(lambda b: struct.pack_into("<Q", b, off_w0, blob.size - 256))                        # W0 runs past the end
+    # first int8 layer descriptor: 5 u64 offsets, then rows, rows_pad, cols, n_fix
+    assert struct.unpack_from("<iii", blob, hdr_q0 + 40) == (64, 256, 64)
+    rejects(lambda b: struct.pack_into("<Q", b, hdr_q0, blob.size - 512))                        # weight rows past the end
+    rejects(lambda b: struct.pack_into("<i", b, hdr_q0 + 44, 200))                               # rows_pad not a tile multiple
+    rejects(lambda b: struct.pack_into("<i", b, hdr_q0 + 52, 1 << 28))                           # n_fix beyond the entry list
+
+
+def test_layer_with_millions_of_saturating_pairs_loads(tmp_path):
+    """The reference runs any weights; a layer whose every pair can saturate (all weights equal ->
+    all 127 after quantization) used to be refused at 2^20 listed pairs."""
+    net = F.synth_net([432, 2048, 2048, 2048, 64], seed=3)
+    net.layers[1].weights[:] = 0.5
+    p = str(tmp_path / "allsat.bin")
+    F.write_model_bin(p, net)
+    hm = api.HostModel(p)
+    assert hm.risky_pairs(1) == 2048 * 1024 > (1 << 20)
+    assert hm.risky_pairs(1) == Oracle(p).risky_pairs(1)
+    assert api.host_blob_check(hm.blob())["n_affine"] == 4
