@@ -182,7 +182,12 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
   // (older loads complete first, so every wait that covers stage 0 covers them too).
   char *aux = smem + Cfg::AUX_OFF;
   if (!OUTPUT && wave < 3) {
-    const int bytes = FAST ? kLut2Size : kLutExt;
+    // The range of a 16-byte LDS-DMA access is checked as a whole: with num_records = the table
+    // size, the lane holding the table's last three (FAST) / last one (exact) entries read zeros --
+    // u8 128 instead of 255 for every activation with lin >= 6.395 (found by
+    // test_net_with_every_pair_saturating; rare on trained nets, never on the round-1 fixtures).
+    // The blob pads both tables to 16 bytes (fdnn_model.cpp: place(size + 15)).
+    const int bytes = ((FAST ? kLut2Size : kLutExt) + 15) & ~15;
     const __amdgpu_buffer_rsrc_t rsrc_lut =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(FAST ? p.lut2 : p.lut), 0, bytes, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lut, FDNN_LDS_PTR(aux + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);

@@ -375,7 +375,7 @@ int adopt_blob(std::vector<uint8_t> &&bytes, HostModel *out, std::string *msg) {
     return bad("inconsistent dimensions");
   const uint64_t H = uint64_t(h.hidden), D = uint64_t(h.in_dim);
   if (!inside(h.off_w0, 4 * H * D) || !inside(h.off_b0, 4 * H) || !inside(h.off_shift, 4 * D) || !inside(h.off_scale, 4 * D) ||
-      !inside(h.off_lut, uint64_t(kLutExt)) || !inside(h.off_lut2, uint64_t(kLut2Size)))
+      !inside(h.off_lut, uint64_t(kLutExt) + 15) || !inside(h.off_lut2, uint64_t(kLut2Size) + 15))
     return bad("layer-0 / table sections outside the blob");
   for (int qi = 0; qi < h.n_q; ++qi) {
     const QLayerDesc &d = h.q[qi];

@@ -507,3 +507,75 @@ long long orc_risky_pairs(const orc_model *m, int j) {
     }
   return cnt;
 }
+
+/* ---------------------------------------------------------------- multi-thread timing harness
+ * bench.py's cpu_baseline leg: T native threads, each with its own output buffer, each scoring
+ * `utts` independent utterances of n frames with orc_calculate (context construction + Calculate,
+ * the reference CLI's timed region dnn.cc:64-71; concurrency model of
+ * MultiThreadedStressTest.java:48-61: one shared immutable model, one private context per call).
+ * No interpreter in the timed region.  Returns wall seconds from a common start barrier to the
+ * last thread's finish, and per-thread seconds in per_thread[T] (may be NULL). */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+  const orc_model *m;
+  const float *x;
+  int n, batch, sse, utts;
+  pthread_barrier_t *start;
+  double seconds;
+  int rc;
+} orc_mt_arg;
+
+static double orc_now(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *orc_mt_worker(void *p) {
+  orc_mt_arg *a = (orc_mt_arg *)p;
+  const int O = a->m->layers[a->m->n_layers - 1].out_dim;
+  float *out = (float *)malloc(sizeof(float) * (size_t)a->n * (size_t)O);
+  pthread_barrier_wait(a->start);
+  const double t0 = orc_now();
+  a->rc = out ? 0 : -1;
+  for (int u = 0; u < a->utts && !a->rc; ++u) a->rc = orc_calculate(a->m, a->x, a->n, a->batch, a->sse, out, NULL);
+  a->seconds = orc_now() - t0;
+  free(out);
+  return NULL;
+}
+
+double orc_bench_threads(const orc_model *m, const float *x, int n, int batch, int use_sse, int threads, int utts,
+                         double *per_thread) {
+  if (threads < 1 || utts < 1) return -1.0;
+  pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+  orc_mt_arg *args = (orc_mt_arg *)calloc((size_t)threads, sizeof(orc_mt_arg));
+  pthread_barrier_t start;
+  pthread_barrier_init(&start, NULL, (unsigned)threads + 1);
+  int made = 0;
+  for (int t = 0; t < threads; ++t) {
+    args[t] = (orc_mt_arg){m, x, n, batch, use_sse, utts, &start, 0.0, 0};
+    if (pthread_create(&th[t], NULL, orc_mt_worker, &args[t]) != 0) break;
+    ++made;
+  }
+  if (made != threads) { /* cannot release a barrier sized for `threads`: report failure */
+    for (int t = 0; t < made; ++t) pthread_cancel(th[t]);
+    free(th);
+    free(args);
+    return -1.0;
+  }
+  pthread_barrier_wait(&start);
+  const double t0 = orc_now();
+  int rc = 0;
+  for (int t = 0; t < threads; ++t) {
+    pthread_join(th[t], NULL);
+    rc |= args[t].rc;
+    if (per_thread) per_thread[t] = args[t].seconds;
+  }
+  const double wall = orc_now() - t0;
+  pthread_barrier_destroy(&start);
+  free(th);
+  free(args);
+  return rc ? -1.0 : wall;
+}

@@ -185,3 +185,34 @@ def test_net_with_every_pair_saturating(tmp_models):
     assert np.abs(t["probs"] - want).max() <= TIGHT
     assert np.abs(dnn.calculate(x) - want).max() <= TIGHT
     dnn.delete()
+
+
+@pytest.mark.parametrize("exact_path", [False, True])
+def test_sigmoid_table_ends(tmp_models, exact_path):
+    """Activations far into both tails of the sigmoid (|x| > 6.4 -> table entries 0 and 255,
+    dnn.h:38-41) in the int8 layers: the last entries of the half-step table (fast epilogue) and
+    of the 1281-entry table (exact epilogue, forced by one bias that breaks the int32 bound) sit
+    in the final 16-byte piece of their LDS copy."""
+    net = F.synth_net([432, 128, 128, 128, 200], seed=31)
+    net.layers[1].weights[:] *= 8.0
+    net.layers[2].weights[:] *= 8.0
+    net.layers[1].bias[1::5] = 9.0      # k >= 640 -> 255
+    net.layers[1].bias[2::5] = -9.0     # k <= -640 -> 0
+    if exact_path:
+        net.layers[1].bias[0] = 3.0e7   # |lin| * 200 no longer provably < 2^31 -> exact round()/table path
+        net.layers[2].bias[0] = -3.0e7
+    p = os.path.join(tmp_models, f"tails_{int(exact_path)}.bin")
+    F.write_model_bin(p, net)
+    x = F.synth_features(500, 432, seed=4)
+    want, wt = Oracle(p).calculate(x, taps=True)
+    u = wt["u8_acts"]
+    assert (u[1] == 255).mean() > 0.15 and (u[1] == 0).mean() > 0.15
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    t = dnn.forwardTaps(x)
+    assert (t["u8_acts"] == u).all()
+    assert (t["acc_out"] == wt["acc_out"]).all()
+    ctx = dnn.getNewLazyContext(500)      # production (tap-free) instances
+    ctx.calculateUntilOutput(x)
+    assert (ctx.hiddenActivations() == u[-1]).all()
+    ctx.delete()
+    dnn.delete()
