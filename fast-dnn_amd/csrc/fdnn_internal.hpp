@@ -1,0 +1,111 @@
+// fdnn_internal.hpp -- what the runtime's translation units share: the model / context objects
+// behind the opaque C-ABI handles and the enqueue helpers over them (fdnn_runtime.cpp), used by
+// the multi-stream server loop (fdnn_server.cpp).  Not installed; the boundary is include/fdnn.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/fdnn.h"
+#include "fdnn_kernels.hpp"
+#include "fdnn_model.hpp"
+
+namespace fdnn {
+
+int fail(int code, const std::string &msg);  // sets fdnn_last_error() of the calling thread, returns code
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return ::fdnn::fail(FDNN_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+  } while (0)
+
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct DeviceGuard {
+  int prev = 0;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
+  }
+  ~DeviceGuard() {
+    if (ok) hipSetDevice(prev);
+  }
+};
+
+}  // namespace fdnn
+
+struct fdnn_model {
+  fdnn::HostModel hm;  // header + host copy of the blob (kept: export, host queries)
+  int device = 0;
+  uint8_t *d_blob = nullptr;
+  float *d_w0t = nullptr;  // layer-0 weights as a chain-major image [4][l0_j_pad][l0_h_ld] (fdnn_l0.hip)
+  int l0_jc = 0, l0_j_pad = 0, l0_h_ld = 0;
+  int l0_fma = 0;
+  int l0_kernel = 0;  // fdnn_debug_set_l0_kernel
+  std::mutex mu;
+  std::vector<fdnn_ctx *> pool;  // idle contexts owned by the model (fdnn_calculate*)
+  // per-kernel HIP-event timing (fdnn_profile_begin/end); off in production
+  bool profiling = false;
+  struct ProfRec {
+    int kind;
+    hipEvent_t a, b;
+  };
+  std::vector<ProfRec> prof;
+};
+
+struct fdnn_ctx {
+  fdnn_model *m = nullptr;
+  int n = 0;              // frames in use
+  int cap = 0;            // frames the scratch was allocated for (padded)
+  int act_ld = 0;
+  hipStream_t stream = nullptr;   // own stream for the host-pointer entry points
+  hipEvent_t done = nullptr;      // last enqueued work (pool hand-over between streams, ctx_enter/ctx_leave)
+  hipStream_t done_stream = nullptr;  // the stream `done` was last recorded on
+  bool done_valid = false;
+  float *d_x = nullptr;           // [n][D]
+  float *d_xt = nullptr;          // [4][l0_j_pad][xt_ld] layer-0 frame image (shifted, scaled, chain-major)
+  int xt_ld = 0;
+  float *d_l0park = nullptr;      // [xt_ld][l0_h_ld] partial chain sums parked by the layer-0 kernel
+  int8_t *d_act[2] = {nullptr, nullptr};  // [n_pad][act_ld] ping/pong, s8 = u8-128
+  float *d_out = nullptr;         // [n][O]
+  float *d_partial = nullptr;     // [rows_pad/64][n_pad]
+  int8_t *d_mask = nullptr;       // [n][O]
+  int last = -1;                  // d_act index holding the last hidden layer, -1 = not computed
+  bool pooled = false;
+  // per-frame lazy calls (the JNI contract): host-mapped pinned staging for kPinFrames masks and
+  // result rows -- the output kernel reads the mask and the scale kernel writes the probabilities
+  // straight through these, so a call is two launches and one stream sync, no copy commands
+  int8_t *h_mask_pin = nullptr, *d_mask_pin = nullptr;
+  float *h_out_pin = nullptr, *d_out_pin = nullptr;
+};
+constexpr int kPinFrames = 8;
+
+
+namespace fdnn {
+
+struct Taps {
+  float *l0_lin = nullptr;
+  uint8_t *u8_acts = nullptr;   // device [n_hidden][n][H]
+  int32_t *acc_hid = nullptr;   // device [n_hidden-1][n][H]
+  int32_t *acc_out = nullptr;   // device [n][O]
+  float *logits = nullptr;      // device [n][O]
+};
+
+int make_ctx(fdnn_model *m, int n, fdnn_ctx **out);
+void destroy_ctx(fdnn_ctx *c);
+// CalculateUntilLastHiddenLayer (dnn.cc:402-424) enqueued on s.
+int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps);
+// CalculateOutput / LazyOutputActivations (dnn.cc:428-454, :355-392) over frames [first, first+count):
+// the output GEMM (exp(z) rows + partial sums) on s, then the soft-max scale -- on s, or, when
+// `tail` is given, on that stream behind an event (`gemm_done`) recorded on s, so that the
+// HBM-bound scale pass can run under the next batch's layer 0.
+int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out, hipStream_t s, const Taps *taps,
+               float *d_final = nullptr, hipStream_t tail = nullptr, hipEvent_t gemm_done = nullptr);
+hipError_t ctx_enter(fdnn_ctx *c, hipStream_t s);
+void ctx_leave(fdnn_ctx *c, hipStream_t s);
+
+}  // namespace fdnn

@@ -16,95 +16,38 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/fdnn.h"
-#include "fdnn_kernels.hpp"
-#include "fdnn_model.hpp"
+#include "fdnn_internal.hpp"
 
 namespace {
-
 thread_local std::string g_err;
+}  // namespace
 
+namespace fdnn {
 int fail(int code, const std::string &msg) {
   g_err = msg;
   return code;
 }
+}  // namespace fdnn
 
-#define HIP_TRY(expr)                                                                                   \
-  do {                                                                                                  \
-    hipError_t e_ = (expr);                                                                             \
-    if (e_ != hipSuccess)                                                                               \
-      return fail(FDNN_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                    \
-  } while (0)
-
-inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
-
-}  // namespace
+using fdnn::DeviceGuard;
+using fdnn::fail;
+using fdnn::round_up;
+using fdnn::Taps;
+using fdnn::ctx_enter;
+using fdnn::ctx_leave;
+using fdnn::destroy_ctx;
+using fdnn::make_ctx;
+using fdnn::run_hidden;
+using fdnn::run_output;
 
 struct fdnn_host_model {
   fdnn::HostModel hm;
 };
 
-struct fdnn_model {
-  fdnn::HostModel hm;  // header + host copy of the blob (kept: export, host queries)
-  int device = 0;
-  uint8_t *d_blob = nullptr;
-  float *d_w0t = nullptr;  // layer-0 weights as a chain-major image [4][l0_j_pad][l0_h_ld] (fdnn_l0.hip)
-  int l0_jc = 0, l0_j_pad = 0, l0_h_ld = 0;
-  int l0_fma = 0;
-  int l0_kernel = 0;  // fdnn_debug_set_l0_kernel
-  std::mutex mu;
-  std::vector<fdnn_ctx *> pool;  // idle contexts owned by the model (fdnn_calculate*)
-  // per-kernel HIP-event timing (fdnn_profile_begin/end); off in production
-  bool profiling = false;
-  struct ProfRec {
-    int kind;
-    hipEvent_t a, b;
-  };
-  std::vector<ProfRec> prof;
-};
-
-struct fdnn_ctx {
-  fdnn_model *m = nullptr;
-  int n = 0;              // frames in use
-  int cap = 0;            // frames the scratch was allocated for (padded)
-  int act_ld = 0;
-  hipStream_t stream = nullptr;   // own stream for the host-pointer entry points
-  hipEvent_t done = nullptr;      // last enqueued work (pool hand-over between streams, ctx_enter/ctx_leave)
-  hipStream_t done_stream = nullptr;  // the stream `done` was last recorded on
-  bool done_valid = false;
-  float *d_x = nullptr;           // [n][D]
-  float *d_xt = nullptr;          // [4][l0_j_pad][xt_ld] layer-0 frame image (shifted, scaled, chain-major)
-  int xt_ld = 0;
-  float *d_l0park = nullptr;      // [xt_ld][l0_h_ld] partial chain sums parked by the layer-0 kernel
-  int8_t *d_act[2] = {nullptr, nullptr};  // [n_pad][act_ld] ping/pong, s8 = u8-128
-  float *d_out = nullptr;         // [n][O]
-  float *d_partial = nullptr;     // [rows_pad/64][n_pad]
-  int8_t *d_mask = nullptr;       // [n][O]
-  int last = -1;                  // d_act index holding the last hidden layer, -1 = not computed
-  bool pooled = false;
-  // per-frame lazy calls (the JNI contract): host-mapped pinned staging for kPinFrames masks and
-  // result rows -- the output kernel reads the mask and the scale kernel writes the probabilities
-  // straight through these, so a call is two launches and one stream sync, no copy commands
-  int8_t *h_mask_pin = nullptr, *d_mask_pin = nullptr;
-  float *h_out_pin = nullptr, *d_out_pin = nullptr;
-};
-constexpr int kPinFrames = 8;
-
-namespace {
+namespace fdnn {
 
 using fdnn::BlobHeader;
 using fdnn::QLayerDesc;
-
-struct DeviceGuard {
-  int prev = 0;
-  bool ok = false;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess) ok = true;
-  }
-  ~DeviceGuard() {
-    if (ok) hipSetDevice(prev);
-  }
-};
 
 int build_l0_image(fdnn_model *m);
 
@@ -249,14 +192,6 @@ struct ProfScope {
   }
 };
 
-struct Taps {
-  float *l0_lin = nullptr;
-  uint8_t *u8_acts = nullptr;   // device [n_hidden][n][H]
-  int32_t *acc_hid = nullptr;   // device [n_hidden-1][n][H]
-  int32_t *acc_out = nullptr;   // device [n][O]
-  float *logits = nullptr;      // device [n][O]
-};
-
 // one device-side u8 snapshot of the s8 activation buffer (taps only)
 int snapshot_acts(const fdnn_ctx *c, int buf, uint8_t *d_dst, hipStream_t s) {
   const BlobHeader &h = c->m->hm.hdr;
@@ -359,7 +294,7 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
 // Rows [first+count, first+n_pad) are read by the GEMM as padding frames; the
 // activation buffers carry one tile of slack rows for that.
 int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out, hipStream_t s, const Taps *taps,
-               float *d_final = nullptr) {  // d_final: where the probabilities go (default: in place in d_out)
+               float *d_final, hipStream_t tail, hipEvent_t gemm_done) {  // d_final: where the probabilities go (default: in place in d_out)
   fdnn_model *m = c->m;
   const BlobHeader &h = m->hm.hdr;
   const QLayerDesc &d = h.q[h.n_q - 1];
@@ -377,9 +312,15 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
     ProfScope ps(m, s, FDNN_PROF_OUTPUT);
     fdnn::launch_qgemm_output(g, s);
   }
+  hipStream_t ns = s;
+  if (tail && gemm_done) {  // the scale pass goes to the tail stream, behind the GEMM
+    HIP_TRY(hipEventRecord(gemm_done, s));
+    HIP_TRY(hipStreamWaitEvent(tail, gemm_done, 0));
+    ns = tail;
+  }
   {
-    ProfScope ps(m, s, FDNN_PROF_NORMALIZE);
-    fdnn::launch_normalize(d_out, d_final ? d_final : d_out, c->d_partial, count, g.partial_ld, d.rows, d.rows_pad / fdnn::kPartialNodes, s);
+    ProfScope ps(m, ns, FDNN_PROF_NORMALIZE);
+    fdnn::launch_normalize(d_out, d_final ? d_final : d_out, c->d_partial, count, g.partial_ld, d.rows, d.rows_pad / fdnn::kPartialNodes, ns);
   }
   HIP_TRY(hipGetLastError());
   return FDNN_OK;
@@ -481,7 +422,9 @@ void release_ctx(fdnn_ctx *c, hipStream_t s) {
   }
 }
 
-}  // namespace
+}  // namespace fdnn
+
+using namespace fdnn;
 
 // =====================================================================  C-ABI
 extern "C" {
