@@ -72,6 +72,15 @@ SIGNATURES = {
     "fdnn_ctx_output": (C.c_int, [C.c_void_p, _c_f32p]),
     "fdnn_ctx_output_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "fdnn_ctx_read_hidden": (C.c_int, [C.c_void_p, _c_u8p]),
+    "fdnn_server_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "fdnn_server_free": (None, [C.c_void_p]),
+    "fdnn_server_set_linger_us": (C.c_int, [C.c_void_p, C.c_int]),
+    "fdnn_server_submit_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
+    "fdnn_server_submit": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_i8p, _c_f32p, C.POINTER(C.c_uint64)]),
+    "fdnn_server_wait": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "fdnn_server_drain": (C.c_int, [C.c_void_p]),
+    "fdnn_server_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "fdnn_model_enable_batcher": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "fdnn_model_blob_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "fdnn_model_export_blob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fdnn_model_import_blob": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
@@ -216,6 +225,66 @@ class LazyContext:
             self.handle = None
 
 
+class ScoringServer:
+    """Multi-stream scoring loop over one model (``fdnn_server_*``): up to ``depth`` batches in
+    flight, the soft-max scale of one batch under layer 0 of the next, host submissions from any
+    number of threads coalesced into full batches.  Generalises ``QuantizedDnn.LazyContext`` /
+    the caller-thread model of MultiThreadedStressTest.java to many utterances per GPU."""
+
+    def __init__(self, dnn: "QuantizedDnn", max_frames: int, depth: int = 2, linger_us: int = 0):
+        h = C.c_void_p()
+        _check(lib().fdnn_server_create(dnn.nativeDnnHandle, max_frames, depth, C.byref(h)))
+        self.handle = h.value
+        self.dnn = dnn
+        self._keep = {}  # ticket -> arrays that must outlive the submission
+        if linger_us:
+            _check(lib().fdnn_server_set_linger_us(self.handle, linger_us))
+
+    def submit_device(self, d_x: int, n: int, d_out: int, d_masks: int = 0) -> int:
+        t = C.c_uint64()
+        _check(lib().fdnn_server_submit_device(self.handle, C.c_void_p(d_x), n, C.c_void_p(d_masks) if d_masks else None,
+                                               C.c_void_p(d_out), C.byref(t)))
+        return int(t.value)
+
+    def submit(self, x, masks=None):
+        """Host frames -> (ticket, out array).  ``out`` is valid after ``wait(ticket)``."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.dnn.inputDimension():
+            raise ValueError(f"Input vector size {x.shape[-1]} must be equal with network input size {self.dnn.inputDimension()}")
+        O = self.dnn.outputDimension()
+        m = None
+        if masks is not None:
+            m = np.ascontiguousarray(masks, dtype=np.int8)
+            if m.shape != (x.shape[0], O):
+                raise ValueError(f"masks must be {x.shape[0]} x {O}, got {m.shape}")
+        out = np.empty((x.shape[0], O), dtype=np.float32)
+        t = C.c_uint64()
+        _check(lib().fdnn_server_submit(self.handle, x.ctypes.data_as(_c_f32p), x.shape[0],
+                                        m.ctypes.data_as(_c_i8p) if m is not None else None, out.ctypes.data_as(_c_f32p), C.byref(t)))
+        self._keep[int(t.value)] = (x, m, out)
+        return int(t.value), out
+
+    def wait(self, ticket: int) -> None:
+        try:
+            _check(lib().fdnn_server_wait(self.handle, ticket))
+        finally:
+            self._keep.pop(ticket, None)
+
+    def drain(self) -> None:
+        _check(lib().fdnn_server_drain(self.handle))
+        self._keep.clear()
+
+    def stats(self) -> dict:
+        v = [C.c_uint64() for _ in range(4)]
+        _check(lib().fdnn_server_stats(self.handle, *[C.byref(a) for a in v]))
+        return dict(zip(("batches", "frames", "requests", "coalesced_requests"), (int(a.value) for a in v)))
+
+    def close(self) -> None:
+        if self.handle:
+            lib().fdnn_server_free(self.handle)
+            self.handle = None
+
+
 class QuantizedDnn:
     """``suskun.nn.QuantizedDnn`` (QuantizedDnn.java) on one MI355X."""
 
@@ -261,6 +330,10 @@ class QuantizedDnn:
 
     def layerCount(self) -> int:
         return lib().fdnn_model_layer_count(self.nativeDnnHandle)
+
+    def enableBatcher(self, max_frames: int, depth: int = 2, linger_us: int = 0) -> None:
+        """Route ``calculate`` through an internal coalescing server (also: FDNN_BATCHER env at load)."""
+        _check(lib().fdnn_model_enable_batcher(self.nativeDnnHandle, max_frames, depth, linger_us))
 
     def setInputLayerFma(self, on: bool) -> None:
         _check(lib().fdnn_model_set_l0_fma(self.nativeDnnHandle, int(on)))

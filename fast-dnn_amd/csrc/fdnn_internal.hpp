@@ -48,6 +48,7 @@ struct fdnn_model {
   int l0_kernel = 0;  // fdnn_debug_set_l0_kernel
   std::mutex mu;
   std::vector<fdnn_ctx *> pool;  // idle contexts owned by the model (fdnn_calculate*)
+  struct fdnn_server *batcher = nullptr;  // fdnn_model_enable_batcher: fdnn_calculate goes through it
   // per-kernel HIP-event timing (fdnn_profile_begin/end); off in production
   bool profiling = false;
   struct ProfRec {

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -456,6 +457,16 @@ int fdnn_model_load_on(const char *path, float cutoff, int device, fdnn_model **
     delete m;
     return rc;
   }
+  if (const char *env = std::getenv("FDNN_BATCHER")) {  // max_frames[:depth[:linger_us]]
+    int mf = 0, depth = 2, linger = 0;
+    if (std::sscanf(env, "%d:%d:%d", &mf, &depth, &linger) >= 1 && mf > 0) {
+      rc = fdnn_model_enable_batcher(m, mf, depth, linger);
+      if (rc) {
+        fdnn_model_free(m);
+        return rc;
+      }
+    }
+  }
   *out = m;
   return FDNN_OK;
 }
@@ -466,8 +477,24 @@ int fdnn_model_load(const char *path, float cutoff, fdnn_model **out) {
   return fdnn_model_load_on(path, cutoff, dev, out);
 }
 
+int fdnn_model_enable_batcher(fdnn_model *m, int max_frames, int depth, int linger_us) {
+  if (!m) return fail(FDNN_E_ARG, "null model");
+  if (m->batcher) return fail(FDNN_E_STATE, "the model already has a batcher");
+  fdnn_server *srv = nullptr;
+  int rc = fdnn_server_create(m, max_frames, depth, &srv);
+  if (!rc) rc = fdnn_server_set_linger_us(srv, linger_us);
+  if (rc) {
+    fdnn_server_free(srv);
+    return rc;
+  }
+  m->batcher = srv;
+  return FDNN_OK;
+}
+
 void fdnn_model_free(fdnn_model *m) {
   if (!m) return;
+  if (m->batcher) fdnn_server_free(m->batcher);
+  m->batcher = nullptr;
   for (fdnn_ctx *c : m->pool) destroy_ctx(c);
   m->pool.clear();
   {
@@ -687,6 +714,12 @@ int fdnn_calculate(fdnn_model *m, const float *x, int n, int dim, int batch_hint
   if (dim != h.in_dim)  // QuantizedDnn.java:157-161
     return fail(FDNN_E_ARG, "input vector size " + std::to_string(dim) + " must be equal with network input size " +
                                 std::to_string(h.in_dim));
+  if (m->batcher) {  // coalesced with the other callers' utterances (fdnn_server.cpp)
+    uint64_t ticket = 0;
+    int brc = fdnn_server_submit(m->batcher, x, n, nullptr, out, &ticket);
+    if (!brc) brc = fdnn_server_wait(m->batcher, ticket);
+    return brc;
+  }
   DeviceGuard g(m->device);
   fdnn_ctx *c = nullptr;
   int rc = acquire_ctx(m, n, &c);

@@ -1,0 +1,513 @@
+// fdnn_server.cpp -- the multi-stream scoring loop: many utterances in flight
+// on one MI355X behind one model handle.
+//
+// The reference's serving shape is caller-side threads over independent utterances, one
+// CalculationContext per call (QuantizedDnn.java:72-107, MultiThreadedStressTest.java:48-69), and
+// the README blames the per-call round trips for what the lazy path fails to gain (README.md:45).
+// On the GPU the same shape wants two things the per-call API cannot give:
+//
+//   * batches in flight.  A full-size batch fills the chip kernel by kernel, so consecutive
+//     batches are serialised on one compute stream; but the soft-max scale of batch i is a pure
+//     HBM pass with the matrix and vector pipes idle, and layer 0 of batch i+1 is a pure fp32
+//     VALU kernel with HBM idle.  The scale pass therefore goes to a tail stream, behind an event,
+//     and runs under the next batch's layer 0.  That needs per-batch scratch (a context per
+//     slot) and a completion handle per batch instead of "the stream is the handle": tickets.
+//   * coalescing.  A 100-frame utterance is 1/100 of a launch that fills the chip.  Host-pointer
+//     submissions from any number of threads are queued, packed into one batch per slot (up to
+//     max_frames), scored once, and scattered back to the callers' buffers.  Frames are
+//     independent and every kernel is batch-size invariant (tests: any split of a batch gives the
+//     same bits), so a coalesced utterance is bit-identical to the same utterance scored alone.
+//
+// Small batches (too few tiles to fill the chip) run whole on the slot's own stream instead, so
+// that several of them overlap.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "fdnn_internal.hpp"
+
+using fdnn::DeviceGuard;
+using fdnn::fail;
+
+namespace {
+
+// below this many frames a batch leaves most CUs idle: run it on its own stream next to others
+constexpr int kSmallBatch = 2560;
+
+struct Piece {  // one caller's rows inside a coalesced batch
+  uint64_t ticket;
+  float *out;      // caller's destination of these rows
+  int row0, rows;  // rows [row0, row0 + rows) of the batch
+  bool last;       // completes the ticket
+};
+
+struct Request {
+  uint64_t ticket;
+  const float *x;
+  const int8_t *masks;  // may be null
+  float *out;
+  int n;
+  int taken = 0;  // frames already packed into earlier batches
+};
+
+struct Slot {
+  fdnn_ctx *ctx = nullptr;
+  hipStream_t stream = nullptr;   // small batches: the whole batch; host batches: copies
+  hipEvent_t gemm_done = nullptr, staged = nullptr, done = nullptr;
+  uint64_t ticket = 0;            // device submissions: the ticket this slot last carried
+  bool used = false;              // `done` has been recorded at least once
+  // host submissions (allocated on first use)
+  float *h_x = nullptr, *h_out = nullptr, *d_out = nullptr;
+  int8_t *h_mask = nullptr;
+  std::vector<Piece> pieces;
+  int frames = 0;
+  bool in_flight = false;         // host batch enqueued, not yet scattered
+};
+
+}  // namespace
+
+struct fdnn_server {
+  fdnn_model *m = nullptr;
+  int max_frames = 0, depth = 0;
+  hipStream_t s_main = nullptr, s_tail = nullptr;
+  std::vector<Slot> slots;
+  std::mutex mu;                  // submission order + slot table
+  uint64_t next_ticket = 1;
+  uint64_t next_slot = 0;       // device submissions (under mu)
+  uint64_t host_next_slot = 0;  // host batches (under qmu)
+  // host path
+  std::mutex qmu;
+  std::condition_variable qcv, done_cv, slot_cv;
+  std::deque<Request> queue;
+  std::deque<int> flying;         // slots with a host batch enqueued, in launch order
+  std::unordered_map<uint64_t, int> pending;  // host ticket -> 0 running, >0 failed with that status
+  std::thread packer, finisher;
+  bool stop = false;
+  bool host_ready = false;
+  int linger_us = 0;
+  // statistics
+  std::atomic<uint64_t> n_batches{0}, n_frames{0}, n_requests{0}, n_coalesced{0};
+};
+
+namespace {
+
+int alloc_host_side(fdnn_server *s) {
+  const fdnn::BlobHeader &h = s->m->hm.hdr;
+  for (Slot &sl : s->slots) {
+    const size_t n = size_t(s->max_frames);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_x), sizeof(float) * n * h.in_dim, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_out), sizeof(float) * n * h.out_dim, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_mask), n * h.out_dim, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&sl.d_out), sizeof(float) * n * h.out_dim);
+    if (e != hipSuccess)
+      return fail(e == hipErrorOutOfMemory ? FDNN_E_NOMEM : FDNN_E_DEVICE, std::string("server staging: ") + hipGetErrorString(e));
+  }
+  return FDNN_OK;
+}
+
+// Enqueue one batch that is already on the device.  Large batches: compute on the shared main
+// stream, soft-max scale on the tail stream; small ones: everything on the slot's stream.
+// `after` (may be null) is an event the compute must wait for (the batch's H2D copy);
+// returns with `sl.done` recorded behind the last kernel.
+int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_t *d_masks, float *d_out, hipEvent_t after,
+                  hipStream_t *last_stream) {
+  fdnn_ctx *c = sl.ctx;
+  c->n = n;
+  c->last = -1;
+  const bool small = n <= kSmallBatch;
+  hipStream_t cs = small ? sl.stream : s->s_main;
+  if (after) HIP_TRY(hipStreamWaitEvent(cs, after, 0));
+  HIP_TRY(fdnn::ctx_enter(c, cs));
+  int rc = fdnn::run_hidden(c, d_x, cs, nullptr);
+  hipStream_t end = cs;
+  if (!rc) {
+    if (small) {
+      rc = fdnn::run_output(c, 0, n, d_masks, d_out, cs, nullptr);
+    } else {
+      rc = fdnn::run_output(c, 0, n, d_masks, d_out, cs, nullptr, nullptr, s->s_tail, sl.gemm_done);
+      end = s->s_tail;
+    }
+  }
+  fdnn::ctx_leave(c, end);
+  if (rc) return rc;
+  *last_stream = end;
+  return FDNN_OK;
+}
+
+void complete_ticket(fdnn_server *s, uint64_t ticket, int status) {
+  {
+    std::lock_guard<std::mutex> lk(s->qmu);
+    auto it = s->pending.find(ticket);
+    if (it != s->pending.end()) {
+      if (status)
+        it->second = status;  // keep the failure for the waiter
+      else
+        s->pending.erase(it);
+    }
+  }
+  s->done_cv.notify_all();
+}
+
+// Packs queued requests into batches and enqueues them.
+void packer_loop(fdnn_server *s) {
+  DeviceGuard g(s->m->device);
+  const fdnn::BlobHeader &h = s->m->hm.hdr;
+  const size_t D = size_t(h.in_dim), O = size_t(h.out_dim);
+  for (;;) {
+    std::unique_lock<std::mutex> lk(s->qmu);
+    s->qcv.wait(lk, [&] { return s->stop || !s->queue.empty(); });
+    if (s->stop && s->queue.empty()) return;
+    if (s->linger_us > 0 && !s->stop) {  // give concurrent callers a moment to join the batch
+      size_t have = 0;
+      for (const Request &r : s->queue) have += size_t(r.n - r.taken);
+      if (have < size_t(s->max_frames))
+        s->qcv.wait_for(lk, std::chrono::microseconds(s->linger_us), [&] {
+          size_t hv = 0;
+          for (const Request &r : s->queue) hv += size_t(r.n - r.taken);
+          return s->stop || hv >= size_t(s->max_frames);
+        });
+    }
+    // a free slot (its previous host batch scattered)
+    int si = -1;
+    s->slot_cv.wait(lk, [&] {
+      for (int k = 0; k < s->depth; ++k) {
+        const int cand = int((s->host_next_slot + uint64_t(k)) % uint64_t(s->depth));
+        if (!s->slots[size_t(cand)].in_flight) {
+          si = cand;
+          return true;
+        }
+      }
+      return s->stop;
+    });
+    if (si < 0) return;
+    Slot &sl = s->slots[size_t(si)];
+    // take requests, whole or in part, until the batch is full
+    std::vector<Request> taken;
+    sl.pieces.clear();
+    int rows = 0;
+    bool any_mask = false;
+    while (!s->queue.empty() && rows < s->max_frames) {
+      Request &r = s->queue.front();
+      const int take = std::min(r.n - r.taken, s->max_frames - rows);
+      Request part = r;
+      part.taken = r.taken;
+      part.n = take;  // rows of this request in THIS batch
+      taken.push_back(part);
+      any_mask |= r.masks != nullptr;
+      r.taken += take;
+      const bool last = r.taken == r.n;
+      sl.pieces.push_back(Piece{r.ticket, r.out + size_t(part.taken) * O, rows, take, last});
+      rows += take;
+      if (last) s->queue.pop_front();
+    }
+    sl.frames = rows;
+    sl.in_flight = true;
+    s->host_next_slot = uint64_t(si) + 1;
+    lk.unlock();
+
+    // stage (pinned), copy, compute, copy back -- all asynchronous from here
+    int r0 = 0;
+    for (const Request &r : taken) {
+      std::memcpy(sl.h_x + size_t(r0) * D, r.x + size_t(r.taken) * D, sizeof(float) * size_t(r.n) * D);
+      if (any_mask) {
+        if (r.masks)
+          std::memcpy(sl.h_mask + size_t(r0) * O, r.masks + size_t(r.taken) * O, size_t(r.n) * O);
+        else
+          std::memset(sl.h_mask + size_t(r0) * O, 1, size_t(r.n) * O);  // dense caller inside a lazy batch: all active
+      }
+      r0 += r.n;
+    }
+    int rc = FDNN_OK;
+    hipError_t e = hipSuccess;
+    {
+      std::lock_guard<std::mutex> order(s->mu);  // launch order against device submissions
+      fdnn_ctx *c = sl.ctx;
+      e = hipMemcpyAsync(c->d_x, sl.h_x, sizeof(float) * size_t(rows) * D, hipMemcpyHostToDevice, sl.stream);
+      if (e == hipSuccess && any_mask) e = hipMemcpyAsync(c->d_mask, sl.h_mask, size_t(rows) * O, hipMemcpyHostToDevice, sl.stream);
+      if (e == hipSuccess) e = hipEventRecord(sl.staged, sl.stream);
+      hipStream_t last = sl.stream;
+      if (e == hipSuccess) rc = enqueue_batch(s, sl, c->d_x, rows, any_mask ? c->d_mask : nullptr, sl.d_out, sl.staged, &last);
+      if (e == hipSuccess && !rc) {
+        if (last != sl.stream) {  // results leave on the slot's stream, behind the tail stream's scale pass
+          e = hipEventRecord(sl.gemm_done, last);  // (gemm_done is free again: the scale pass already waits on its earlier record)
+          if (e == hipSuccess) e = hipStreamWaitEvent(sl.stream, sl.gemm_done, 0);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(float) * size_t(rows) * O, hipMemcpyDeviceToHost, sl.stream);
+        if (e == hipSuccess) e = hipEventRecord(sl.done, sl.stream);
+      }
+    }
+    if (e != hipSuccess) rc = fail(FDNN_E_DEVICE, std::string("server batch: ") + hipGetErrorString(e));
+    s->n_batches++;
+    s->n_frames += uint64_t(rows);
+    if (taken.size() > 1) s->n_coalesced += taken.size();
+    {
+      std::lock_guard<std::mutex> lk2(s->qmu);
+      if (rc) {  // nothing usable was enqueued: fail the tickets, free the slot
+        sl.in_flight = false;
+        for (const Piece &p : sl.pieces) {
+          auto it = s->pending.find(p.ticket);
+          if (it != s->pending.end()) it->second = rc;
+        }
+      } else {
+        s->flying.push_back(si);
+      }
+    }
+    if (rc) {
+      s->done_cv.notify_all();
+      s->slot_cv.notify_all();
+    } else {
+      s->qcv.notify_all();  // wakes the finisher
+    }
+  }
+}
+
+// Waits for enqueued host batches in launch order and hands the rows back.
+void finisher_loop(fdnn_server *s) {
+  DeviceGuard g(s->m->device);
+  const size_t O = size_t(s->m->hm.hdr.out_dim);
+  for (;;) {
+    int si;
+    {
+      std::unique_lock<std::mutex> lk(s->qmu);
+      s->qcv.wait(lk, [&] { return s->stop || !s->flying.empty(); });
+      if (s->flying.empty()) {
+        if (s->stop) return;
+        continue;
+      }
+      si = s->flying.front();
+      s->flying.pop_front();
+    }
+    Slot &sl = s->slots[size_t(si)];
+    const hipError_t e = hipEventSynchronize(sl.done);
+    const int status = e == hipSuccess ? FDNN_OK : FDNN_E_DEVICE;
+    for (const Piece &p : sl.pieces) {
+      if (!status) std::memcpy(p.out, sl.h_out + size_t(p.row0) * O, sizeof(float) * size_t(p.rows) * O);
+      if (p.last || status) complete_ticket(s, p.ticket, status);
+    }
+    {
+      std::lock_guard<std::mutex> lk(s->qmu);
+      sl.in_flight = false;
+    }
+    s->slot_cv.notify_all();
+  }
+}
+
+int start_host_side(fdnn_server *s) {
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (s->host_ready) return FDNN_OK;
+  int rc = alloc_host_side(s);
+  if (rc) return rc;
+  s->packer = std::thread(packer_loop, s);
+  s->finisher = std::thread(finisher_loop, s);
+  s->host_ready = true;
+  return FDNN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fdnn_server_create(fdnn_model *m, int max_frames, int depth, fdnn_server **out) {
+  if (!m || !out) return fail(FDNN_E_ARG, "null argument");
+  *out = nullptr;
+  if (max_frames <= 0 || depth < 1 || depth > 16) return fail(FDNN_E_ARG, "server needs max_frames > 0 and 1 <= depth <= 16");
+  DeviceGuard g(m->device);
+  if (!g.ok) return fail(FDNN_E_DEVICE, "hipSetDevice failed");
+  std::unique_ptr<fdnn_server> s(new fdnn_server());
+  s->m = m;
+  s->max_frames = max_frames;
+  s->depth = depth;
+  s->slots.resize(size_t(depth));
+  hipError_t e = hipStreamCreateWithFlags(&s->s_main, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->s_tail, hipStreamNonBlocking);
+  int rc = FDNN_OK;
+  for (Slot &sl : s->slots) {
+    if (e != hipSuccess || rc) break;
+    rc = fdnn::make_ctx(m, max_frames, &sl.ctx);
+    if (rc) break;
+    e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.gemm_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.staged, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
+  }
+  if (e != hipSuccess && !rc) rc = fail(FDNN_E_DEVICE, std::string("server: ") + hipGetErrorString(e));
+  if (rc) {
+    fdnn_server_free(s.release());
+    return rc;
+  }
+  *out = s.release();
+  return FDNN_OK;
+}
+
+void fdnn_server_free(fdnn_server *s) {
+  if (!s) return;
+  DeviceGuard g(s->m->device);
+  {
+    std::lock_guard<std::mutex> lk(s->qmu);
+    s->stop = true;
+  }
+  s->qcv.notify_all();
+  s->slot_cv.notify_all();
+  if (s->packer.joinable()) s->packer.join();
+  if (s->finisher.joinable()) s->finisher.join();
+  for (Slot &sl : s->slots) {
+    if (sl.used && sl.done) hipEventSynchronize(sl.done);
+    if (sl.stream) hipStreamSynchronize(sl.stream);
+  }
+  if (s->s_main) hipStreamSynchronize(s->s_main);
+  if (s->s_tail) hipStreamSynchronize(s->s_tail);
+  for (Slot &sl : s->slots) {
+    if (sl.ctx) fdnn::destroy_ctx(sl.ctx);
+    if (sl.h_x) hipHostFree(sl.h_x);
+    if (sl.h_out) hipHostFree(sl.h_out);
+    if (sl.h_mask) hipHostFree(sl.h_mask);
+    if (sl.d_out) hipFree(sl.d_out);
+    if (sl.gemm_done) hipEventDestroy(sl.gemm_done);
+    if (sl.staged) hipEventDestroy(sl.staged);
+    if (sl.done) hipEventDestroy(sl.done);
+    if (sl.stream) hipStreamDestroy(sl.stream);
+  }
+  if (s->s_main) hipStreamDestroy(s->s_main);
+  if (s->s_tail) hipStreamDestroy(s->s_tail);
+  delete s;
+}
+
+int fdnn_server_set_linger_us(fdnn_server *s, int microseconds) {
+  if (!s || microseconds < 0) return fail(FDNN_E_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(s->qmu);
+  s->linger_us = microseconds;
+  return FDNN_OK;
+}
+
+int fdnn_server_submit_device(fdnn_server *s, const float *d_x, int n, const int8_t *d_masks, float *d_out, uint64_t *ticket) {
+  if (!s || !ticket) return fail(FDNN_E_ARG, "null argument");
+  if (n <= 0 || n > s->max_frames) return fail(FDNN_E_ARG, "frame count must be in 1..max_frames of the server");
+  if (!d_x || !d_out) return fail(FDNN_E_ARG, "null buffer");
+  DeviceGuard g(s->m->device);
+  std::unique_lock<std::mutex> lk(s->mu);
+  // next slot in submission order; its previous batch must have completed (that bounds the batches in flight)
+  int si = -1;
+  for (;;) {
+    const int cand = int(s->next_slot % uint64_t(s->depth));
+    Slot &c = s->slots[size_t(cand)];
+    bool host_busy;
+    {
+      std::lock_guard<std::mutex> q(s->qmu);
+      host_busy = c.in_flight;
+    }
+    if (!host_busy) {
+      si = cand;
+      break;
+    }
+    lk.unlock();  // a host batch owns it: wait for the finisher, then look again
+    {
+      std::unique_lock<std::mutex> q(s->qmu);
+      s->slot_cv.wait(q, [&] { return !s->slots[size_t(cand)].in_flight; });
+    }
+    lk.lock();
+  }
+  Slot &sl = s->slots[size_t(si)];
+  if (sl.used) HIP_TRY(hipEventSynchronize(sl.done));
+  hipStream_t last = nullptr;
+  int rc = enqueue_batch(s, sl, d_x, n, d_masks, d_out, nullptr, &last);
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(sl.done, last));
+  sl.used = true;
+  sl.ticket = s->next_ticket++;
+  s->next_slot = uint64_t(si) + 1;
+  *ticket = sl.ticket;
+  s->n_batches++;
+  s->n_frames += uint64_t(n);
+  s->n_requests++;
+  return FDNN_OK;
+}
+
+int fdnn_server_submit(fdnn_server *s, const float *x, int n, const int8_t *masks, float *out, uint64_t *ticket) {
+  if (!s || !ticket) return fail(FDNN_E_ARG, "null argument");
+  if (n <= 0) return fail(FDNN_E_ARG, "frame count must be positive");
+  if (!x || !out) return fail(FDNN_E_ARG, "null buffer");
+  int rc = start_host_side(s);
+  if (rc) return rc;
+  uint64_t t;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    t = s->next_ticket++;
+  }
+  {
+    std::lock_guard<std::mutex> lk(s->qmu);
+    s->pending.emplace(t, 0);
+    s->queue.push_back(Request{t, x, masks, out, n, 0});
+  }
+  s->n_requests++;
+  s->qcv.notify_all();
+  *ticket = t;
+  return FDNN_OK;
+}
+
+int fdnn_server_wait(fdnn_server *s, uint64_t ticket) {
+  if (!s) return fail(FDNN_E_ARG, "null argument");
+  {  // a host ticket?
+    std::unique_lock<std::mutex> lk(s->qmu);
+    auto it = s->pending.find(ticket);
+    if (it != s->pending.end()) {
+      s->done_cv.wait(lk, [&] {
+        auto j = s->pending.find(ticket);
+        return j == s->pending.end() || j->second != 0;
+      });
+      auto j = s->pending.find(ticket);
+      if (j == s->pending.end()) return FDNN_OK;
+      const int status = j->second;
+      s->pending.erase(j);
+      return fail(status, "a batch carrying this ticket failed on the device");
+    }
+  }
+  hipEvent_t ev = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (ticket == 0 || ticket >= s->next_ticket) return fail(FDNN_E_ARG, "unknown ticket");
+    for (Slot &sl : s->slots)
+      if (sl.used && sl.ticket == ticket) ev = sl.done;
+  }
+  if (!ev) return FDNN_OK;  // its slot has been reused since: a slot is only reused after completion
+  DeviceGuard g(s->m->device);
+  HIP_TRY(hipEventSynchronize(ev));
+  return FDNN_OK;
+}
+
+int fdnn_server_drain(fdnn_server *s) {
+  if (!s) return fail(FDNN_E_ARG, "null argument");
+  {
+    std::unique_lock<std::mutex> lk(s->qmu);
+    s->done_cv.wait(lk, [&] {
+      for (const auto &kv : s->pending)
+        if (kv.second == 0) return false;
+      return true;
+    });
+  }
+  DeviceGuard g(s->m->device);
+  std::lock_guard<std::mutex> lk(s->mu);
+  for (Slot &sl : s->slots)
+    if (sl.used) HIP_TRY(hipEventSynchronize(sl.done));
+  return FDNN_OK;
+}
+
+int fdnn_server_stats(fdnn_server *s, uint64_t *batches, uint64_t *frames, uint64_t *requests, uint64_t *coalesced_requests) {
+  if (!s) return fail(FDNN_E_ARG, "null argument");
+  if (batches) *batches = s->n_batches.load();
+  if (frames) *frames = s->n_frames.load();
+  if (requests) *requests = s->n_requests.load();
+  if (coalesced_requests) *coalesced_requests = s->n_coalesced.load();
+  return FDNN_OK;
+}
+
+}  // extern "C"

@@ -140,6 +140,48 @@ FDNN_API int fdnn_ctx_output_device(fdnn_ctx *c, float *d_out, void *stream);
 /* Last hidden layer's u8 activations, n x hidden_dim (quantized_activations_). */
 FDNN_API int fdnn_ctx_read_hidden(fdnn_ctx *c, uint8_t *out);
 
+/* ------------------------------------------------------------------ multi-stream scoring loop
+ * Generalises the reference's serving shape -- caller threads over independent
+ * utterances, one context per call (QuantizedDnn.java:72-107,
+ * MultiThreadedStressTest.java:48-69) -- to batches in flight on one GPU.
+ * A server owns `depth` slots (a context sized for max_frames each) and two
+ * shared streams: consecutive large batches are serialised on the compute
+ * stream while the HBM-bound soft-max scale of batch i runs on the tail stream
+ * under the VALU-bound layer 0 of batch i+1; batches too small to fill the chip
+ * run whole on their slot's stream, next to each other.  A submission returns a
+ * ticket; fdnn_server_wait(ticket) returns when its results are complete.
+ * At most `depth` device submissions are in flight: a further submit first
+ * waits for the oldest.  All entry points are thread-safe.
+ *
+ *   fdnn_server_submit_device  d_x [n][input_dim] and d_out [n][output_dim] live
+ *     on the model's device and must stay valid until the ticket completes;
+ *     d_masks (may be NULL) [n][output_dim] selects the lazy contract
+ *     (dnn.cc:355-392).  n <= max_frames.
+ *   fdnn_server_submit         host buffers, any n >= 1.  Submissions from any
+ *     number of threads are coalesced: packed into one batch of up to
+ *     max_frames frames per slot, scored once, scattered back to each caller's
+ *     `out`.  x / masks / out must stay valid until the ticket completes.  A
+ *     coalesced utterance is bit-identical to the same utterance scored alone
+ *     (frames are independent, kernels are batch-size invariant).
+ *   fdnn_server_set_linger_us  how long the packer waits for more host
+ *     submissions before launching a batch that is not full (default 0).
+ *   fdnn_model_enable_batcher  routes fdnn_calculate (= the JNI calculate()) of
+ *     this model through an internal server, so that the unmodified Java class
+ *     called from many threads is coalesced as well; also switched on at load by
+ *     the environment variable FDNN_BATCHER=max_frames[:depth[:linger_us]]. */
+typedef struct fdnn_server fdnn_server;
+FDNN_API int fdnn_server_create(fdnn_model *m, int max_frames, int depth, fdnn_server **out);
+FDNN_API void fdnn_server_free(fdnn_server *s);
+FDNN_API int fdnn_server_set_linger_us(fdnn_server *s, int microseconds);
+FDNN_API int fdnn_server_submit_device(fdnn_server *s, const float *d_x, int n, const int8_t *d_masks, float *d_out,
+                                       uint64_t *ticket);
+FDNN_API int fdnn_server_submit(fdnn_server *s, const float *x, int n, const int8_t *masks, float *out, uint64_t *ticket);
+FDNN_API int fdnn_server_wait(fdnn_server *s, uint64_t ticket);
+FDNN_API int fdnn_server_drain(fdnn_server *s);
+FDNN_API int fdnn_server_stats(fdnn_server *s, uint64_t *batches, uint64_t *frames, uint64_t *requests,
+                               uint64_t *coalesced_requests);
+FDNN_API int fdnn_model_enable_batcher(fdnn_model *m, int max_frames, int depth, int linger_us);
+
 /* ------------------------------------------------------------------ multi-GPU weight distribution
  * Rank 0 quantizes once; the packed blob (header + fp32 layer 0 + int8 layers +
  * per-node offsets + biases + shift/scale + LUT) is broadcast over RCCL by the

@@ -1,0 +1,128 @@
+"""The multi-stream scoring loop (fdnn_server_*): batches in flight and
+coalesced host submissions must give exactly what the per-call API gives -- the serving shape of
+QuantizedDnn.java:72-107 / MultiThreadedStressTest.java:48-69 on one GPU."""
+import threading
+
+import numpy as np
+import pytest
+
+from fast_dnn_amd import api, formats as F
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+TIGHT = 2e-6
+
+
+@pytest.mark.parametrize("depth", [1, 2, 4])
+def test_device_batches_in_flight_are_deterministic(net_model_path, depth):
+    """Full-size batches through the compute/tail stream pair: whatever the in-flight depth, every
+    batch is bit-identical to fdnn_calculate_device on one stream (the soft-max scale running
+    under the next batch's layer 0 touches only its own slot's scratch)."""
+    import torch
+
+    n, O = 6000, 8000
+    xs = [torch.from_numpy(F.synth_features(n, 432, seed=70 + i)).cuda() for i in range(3)]
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    want = []
+    for x in xs:
+        o = torch.empty((n, O), dtype=torch.float32, device="cuda")
+        dnn.calculate_device(x.data_ptr(), n, o.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        want.append(o)
+    torch.cuda.synchronize()
+    srv = api.ScoringServer(dnn, max_frames=n, depth=depth)
+    outs = [torch.zeros((n, O), dtype=torch.float32, device="cuda") for _ in range(9)]
+    torch.cuda.synchronize()
+    tickets = [srv.submit_device(xs[i % 3].data_ptr(), n, outs[i].data_ptr()) for i in range(9)]
+    for t in reversed(tickets):   # any order
+        srv.wait(t)
+    for i in range(9):
+        assert torch.equal(outs[i], want[i % 3]), (depth, i)
+    # lazy contract through the same loop
+    masks = torch.from_numpy(F.generate_masks(300, O, 0.4, 0.03, seed=2)).cuda()
+    ctx = dnn.getNewLazyContext(300)
+    ctx.calculateUntilOutputDevice(xs[0].data_ptr(), 0)
+    ref = torch.empty((300, O), dtype=torch.float32, device="cuda")
+    ctx.calculateForOutputNodesBatchDevice(masks.data_ptr(), ref.data_ptr(), 0, 300, 0)
+    torch.cuda.synchronize()
+    ctx.delete()
+    got = torch.zeros((300, O), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    srv.wait(srv.submit_device(xs[0].data_ptr(), 300, got.data_ptr(), masks.data_ptr()))
+    assert torch.equal(got, ref)
+    with pytest.raises(api.FdnnError):
+        srv.submit_device(xs[0].data_ptr(), n + 1, outs[0].data_ptr())
+    st = srv.stats()
+    assert st["batches"] == 10 and st["frames"] == 9 * n + 300
+    srv.close()
+    dnn.delete()
+
+
+def test_host_submissions_from_many_threads_are_coalesced(mid_model_path):
+    """MultiThreadedStressTest.java:48-69 on the server: 8 threads x ragged utterances (some longer
+    than one batch, some with lazy masks) -> every result bit-identical to the same utterance
+    scored alone through QuantizedDnn.calculate / the lazy context, and equal to the oracle."""
+    dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+    orc = Oracle(mid_model_path)
+    O = dnn.outputDimension()
+    lens = [100, 37, 1, 250, 999, 100, 64, 1300, 100, 2, 511, 100]
+    utts = [F.synth_features(n, 432, seed=400 + i) for i, n in enumerate(lens)]
+    masks = {3: F.generate_masks(lens[3], O, 0.4, 0.03, seed=1), 7: F.generate_masks(lens[7], O, 0.4, 0.03, seed=2)}
+    alone = []
+    for i, x in enumerate(utts):
+        if i in masks:
+            ctx = dnn.getNewLazyContext(len(x))
+            ctx.calculateUntilOutput(x)
+            alone.append(ctx.calculateForOutputNodesBatch(masks[i]))
+            ctx.delete()
+        else:
+            alone.append(dnn.calculate(x))
+    assert np.abs(alone[0] - orc.calculate(utts[0])).max() <= TIGHT
+    assert np.abs(alone[3] - orc.lazy(utts[3], masks[3])).max() <= TIGHT
+    srv = api.ScoringServer(dnn, max_frames=1024, depth=3, linger_us=200)
+    results = [None] * (8 * len(utts))
+    errors = []
+
+    def worker(w):
+        try:
+            for j in range(len(utts)):
+                i = (j + w) % len(utts)
+                t, out = srv.submit(utts[i], masks.get(i))
+                srv.wait(t)
+                results[w * len(utts) + j] = (i, out)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(w,)) for w in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for i, out in results:
+        assert np.array_equal(out, alone[i]), i
+    st = srv.stats()
+    assert st["requests"] == 8 * len(utts)
+    assert st["coalesced_requests"] > 0 and st["batches"] < st["requests"] + 8   # utterances really shared batches
+    srv.close()
+    dnn.delete()
+
+
+def test_calculate_through_the_model_batcher(mid_model_path):
+    """fdnn_model_enable_batcher: the unmodified calculate() entry (what the JNI symbol calls)
+    from 8 threads goes through the coalescing loop and returns the same bits."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    plain = api.QuantizedDnn.loadFromFile(mid_model_path)
+    xs = [F.synth_features(20 + 17 * i, seed=300 + i) for i in range(12)]
+    want = [plain.calculate(x) for x in xs]
+    plain.delete()
+    dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+    dnn.enableBatcher(2048, 2, 100)
+    with pytest.raises(api.FdnnError):
+        dnn.enableBatcher(2048, 2, 100)
+    with ThreadPoolExecutor(8) as ex:
+        got = list(ex.map(lambda i: dnn.calculate(xs[i % 12]), range(96)))
+    for i, g in enumerate(got):
+        assert np.array_equal(g, want[i % 12]), i
+    assert dnn.calculate(np.zeros((0, 432), np.float32)).shape == (0, 0)
+    dnn.delete()
