@@ -81,6 +81,14 @@ SIGNATURES = {
     "fdnn_server_drain": (C.c_int, [C.c_void_p]),
     "fdnn_server_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "fdnn_model_enable_batcher": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "fdnn_group_load": (C.c_int, [C.c_char_p, C.c_float, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "fdnn_group_free": (None, [C.c_void_p]),
+    "fdnn_group_size": (C.c_int, [C.c_void_p]),
+    "fdnn_group_model": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "fdnn_group_weight_transport": (C.c_char_p, [C.c_void_p]),
+    "fdnn_group_calculate": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, C.c_int, _c_f32p]),
+    "fdnn_group_shard": (None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "fdnn_group_attach": (C.c_int, [C.c_void_p]),
     "fdnn_model_blob_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "fdnn_model_export_blob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fdnn_model_import_blob": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
@@ -222,6 +230,54 @@ class LazyContext:
     def delete(self) -> None:
         if self.handle:
             lib().fdnn_ctx_free(self.handle)
+            self.handle = None
+
+
+def group_shard(n: int, world: int, rank: int):
+    """[start, stop) of one device's contiguous frame shard (``fdnn_group_shard``)."""
+    a, b = C.c_int(), C.c_int()
+    lib().fdnn_group_shard(n, world, rank, C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
+
+
+class DeviceGroup:
+    """One process, several devices of one node (``fdnn_group_*``): weights quantized once and sent
+    device-to-device at load, the frames of each ``calculate`` call sharded over the replicas."""
+
+    def __init__(self, dnnFile: str, devices: Sequence[int], weightCutOffValue: float = 3.0):
+        if weightCutOffValue <= 0:
+            raise ValueError(f"Weight cut off value must be positive. But it is {weightCutOffValue}")
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib().fdnn_group_load(os.path.abspath(dnnFile).encode(), weightCutOffValue, arr, len(devices), C.byref(h)))
+        self.handle = h.value
+
+    def size(self) -> int:
+        return lib().fdnn_group_size(self.handle)
+
+    def model(self, index: int) -> "QuantizedDnn":
+        """A view of replica ``index`` (owned by the group: do not delete it)."""
+        return QuantizedDnn(lib().fdnn_group_model(self.handle, index))
+
+    def weightTransport(self) -> str:
+        return lib().fdnn_group_weight_transport(self.handle).decode()
+
+    def calculate(self, input, batchSize: int = 10) -> np.ndarray:
+        x = np.asarray(input, dtype=np.float32)
+        if x.shape[0] == 0:
+            return np.zeros((0, 0), dtype=np.float32)
+        m = self.model(0)
+        if x.ndim != 2 or x.shape[1] != m.inputDimension():
+            raise ValueError(f"Input vector size {x.shape[-1]} must be equal with network input size {m.inputDimension()}")
+        x = np.ascontiguousarray(x)
+        out = np.empty((x.shape[0], m.outputDimension()), dtype=np.float32)
+        _check(lib().fdnn_group_calculate(self.handle, x.ctypes.data_as(_c_f32p), x.shape[0], x.shape[1], batchSize,
+                                          out.ctypes.data_as(_c_f32p)))
+        return out
+
+    def delete(self) -> None:
+        if self.handle:
+            lib().fdnn_group_free(self.handle)
             self.handle = None
 
 

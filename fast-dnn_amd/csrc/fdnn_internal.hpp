@@ -49,6 +49,7 @@ struct fdnn_model {
   std::mutex mu;
   std::vector<fdnn_ctx *> pool;  // idle contexts owned by the model (fdnn_calculate*)
   struct fdnn_server *batcher = nullptr;  // fdnn_model_enable_batcher: fdnn_calculate goes through it
+  struct fdnn_group *group = nullptr;     // fdnn_group_attach: this model leads a device group, fdnn_calculate shards over it
   // per-kernel HIP-event timing (fdnn_profile_begin/end); off in production
   bool profiling = false;
   struct ProfRec {

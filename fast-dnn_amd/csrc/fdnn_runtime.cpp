@@ -423,6 +423,41 @@ void release_ctx(fdnn_ctx *c, hipStream_t s) {
   }
 }
 
+// fdnn_calculate on the model's own device (the group path calls this per shard).
+int calculate_on_one_device(fdnn_model *m, const float *x, int n, int dim, int batch_hint, float *out) {
+  (void)batch_hint;
+  if (!m || n < 0) return fail(FDNN_E_ARG, "bad argument");
+  if (n == 0) return FDNN_OK;  // QuantizedDnn.java:154-156
+  if (!x || !out) return fail(FDNN_E_ARG, "null buffer");
+  const BlobHeader &h = m->hm.hdr;
+  if (dim != h.in_dim)  // QuantizedDnn.java:157-161
+    return fail(FDNN_E_ARG, "input vector size " + std::to_string(dim) + " must be equal with network input size " +
+                                std::to_string(h.in_dim));
+  if (m->batcher) {  // coalesced with the other callers' utterances (fdnn_server.cpp)
+    uint64_t ticket = 0;
+    int brc = fdnn_server_submit(m->batcher, x, n, nullptr, out, &ticket);
+    if (!brc) brc = fdnn_server_wait(m->batcher, ticket);
+    return brc;
+  }
+  DeviceGuard g(m->device);
+  fdnn_ctx *c = nullptr;
+  int rc = acquire_ctx(m, n, &c);
+  if (rc) return rc;
+  hipStream_t s = c->stream;
+  hipError_t e = hipStreamWaitEvent(s, c->done, 0);
+  if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x, sizeof(float) * size_t(n) * dim, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    rc = run_hidden(c, c->d_x, s, nullptr);
+    if (!rc) rc = run_output(c, 0, n, nullptr, c->d_out, s, nullptr);
+    if (!rc) rc = copy_out(out, c->d_out, sizeof(float) * size_t(n) * h.out_dim, s);
+  }
+  if (e == hipSuccess && rc) hipStreamSynchronize(s);
+  release_ctx(c, s);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("fdnn_calculate: ") + hipGetErrorString(e));
+  return FDNN_OK;
+}
+
 }  // namespace fdnn
 
 using namespace fdnn;
@@ -472,6 +507,33 @@ int fdnn_model_load_on(const char *path, float cutoff, int device, fdnn_model **
 }
 
 int fdnn_model_load(const char *path, float cutoff, fdnn_model **out) {
+  // FDNN_DEVICES="0,1,2,3" or "all": one replica per listed device, weights distributed at load,
+  // fdnn_calculate on the returned handle shards its frames over them (fdnn_group.cpp) -- how the
+  // unmodified Java class reaches every GPU of the node.
+  if (const char *env = std::getenv("FDNN_DEVICES")) {
+    std::vector<int> devs;
+    if (std::strcmp(env, "all") == 0) {
+      for (int d = 0; d < fdnn_device_count(); ++d) devs.push_back(d);
+    } else {
+      for (const char *q = env; *q;) {
+        char *end = nullptr;
+        const long v = std::strtol(q, &end, 10);
+        if (end == q) break;
+        devs.push_back(int(v));
+        q = (*end == ',') ? end + 1 : end;
+      }
+    }
+    if (devs.size() > 1) {
+      if (!out) return fail(FDNN_E_ARG, "null argument");
+      fdnn_group *g = nullptr;
+      int rc = fdnn_group_load(path, cutoff, devs.data(), int(devs.size()), &g);
+      if (rc) return rc;
+      fdnn_group_attach(g);
+      *out = fdnn_group_model(g, 0);
+      return FDNN_OK;
+    }
+    if (devs.size() == 1) return fdnn_model_load_on(path, cutoff, devs[0], out);
+  }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   return fdnn_model_load_on(path, cutoff, dev, out);
@@ -493,6 +555,10 @@ int fdnn_model_enable_batcher(fdnn_model *m, int max_frames, int depth, int ling
 
 void fdnn_model_free(fdnn_model *m) {
   if (!m) return;
+  if (m->group) {  // the leader of an attached group: the group owns every replica, this one included
+    fdnn_group_free(m->group);
+    return;
+  }
   if (m->batcher) fdnn_server_free(m->batcher);
   m->batcher = nullptr;
   for (fdnn_ctx *c : m->pool) destroy_ctx(c);
@@ -706,37 +772,11 @@ int fdnn_calculate_device(fdnn_model *m, const float *d_x, int n, float *d_out, 
 }
 
 int fdnn_calculate(fdnn_model *m, const float *x, int n, int dim, int batch_hint, float *out) {
-  (void)batch_hint;
   if (!m || n < 0) return fail(FDNN_E_ARG, "bad argument");
   if (n == 0) return FDNN_OK;  // QuantizedDnn.java:154-156
   if (!x || !out) return fail(FDNN_E_ARG, "null buffer");
-  const BlobHeader &h = m->hm.hdr;
-  if (dim != h.in_dim)  // QuantizedDnn.java:157-161
-    return fail(FDNN_E_ARG, "input vector size " + std::to_string(dim) + " must be equal with network input size " +
-                                std::to_string(h.in_dim));
-  if (m->batcher) {  // coalesced with the other callers' utterances (fdnn_server.cpp)
-    uint64_t ticket = 0;
-    int brc = fdnn_server_submit(m->batcher, x, n, nullptr, out, &ticket);
-    if (!brc) brc = fdnn_server_wait(m->batcher, ticket);
-    return brc;
-  }
-  DeviceGuard g(m->device);
-  fdnn_ctx *c = nullptr;
-  int rc = acquire_ctx(m, n, &c);
-  if (rc) return rc;
-  hipStream_t s = c->stream;
-  hipError_t e = hipStreamWaitEvent(s, c->done, 0);
-  if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x, sizeof(float) * size_t(n) * dim, hipMemcpyHostToDevice, s);
-  if (e == hipSuccess) {
-    rc = run_hidden(c, c->d_x, s, nullptr);
-    if (!rc) rc = run_output(c, 0, n, nullptr, c->d_out, s, nullptr);
-    if (!rc) rc = copy_out(out, c->d_out, sizeof(float) * size_t(n) * h.out_dim, s);
-  }
-  if (e == hipSuccess && rc) hipStreamSynchronize(s);
-  release_ctx(c, s);
-  if (rc) return rc;
-  if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("fdnn_calculate: ") + hipGetErrorString(e));
-  return FDNN_OK;
+  if (m->group) return fdnn_group_calculate(m->group, x, n, dim, batch_hint, out);  // sharded over the node's devices
+  return fdnn::calculate_on_one_device(m, x, n, dim, batch_hint, out);
 }
 
 // ---------------------------------------------------------------- taps

@@ -182,6 +182,31 @@ FDNN_API int fdnn_server_stats(fdnn_server *s, uint64_t *batches, uint64_t *fram
                                uint64_t *coalesced_requests);
 FDNN_API int fdnn_model_enable_batcher(fdnn_model *m, int max_frames, int depth, int linger_us);
 
+/* ------------------------------------------------------------------ one process, N devices of one node
+ * BASELINE north_star: frames shard across the node's GPUs, weights broadcast at
+ * load only.  fdnn_group_load quantizes on devices[0] and sends the packed blob
+ * device-to-device to every other listed device (hipMemcpyPeer over xGMI, or one
+ * ncclBroadcast when FDNN_GROUP_BCAST=rccl); fdnn_group_calculate cuts the n
+ * frames of ONE call (host buffers, as fdnn_calculate / jni_dnn.cc:35-62) into
+ * contiguous shards -- fdnn_group_shard, sizes differ by at most one -- scores
+ * them concurrently, one host thread per device, each into its slice of `out`.
+ * No collective in steady state.  A device may be listed more than once (two
+ * replicas on one GPU: how the protocol is tested on a one-GPU box).
+ * fdnn_group_attach makes the group transparent: fdnn_calculate on
+ * fdnn_group_model(g, 0) shards over the group and fdnn_model_free on it frees
+ * the whole group -- which is what fdnn_model_load does by itself when the
+ * environment variable FDNN_DEVICES lists several devices ("0,1,2,3" / "all"),
+ * so the unmodified Java class scales with no code change. */
+typedef struct fdnn_group fdnn_group;
+FDNN_API int fdnn_group_load(const char *path, float cutoff, const int *devices, int n_devices, fdnn_group **out);
+FDNN_API void fdnn_group_free(fdnn_group *g);
+FDNN_API int fdnn_group_size(const fdnn_group *g);
+FDNN_API fdnn_model *fdnn_group_model(const fdnn_group *g, int index);
+FDNN_API const char *fdnn_group_weight_transport(const fdnn_group *g); /* "none" | "peer-copy" | "rccl" */
+FDNN_API int fdnn_group_calculate(fdnn_group *g, const float *x, int n, int dim, int batch_hint, float *out);
+FDNN_API void fdnn_group_shard(int n, int world, int rank, int *start, int *stop);
+FDNN_API int fdnn_group_attach(fdnn_group *g);
+
 /* ------------------------------------------------------------------ multi-GPU weight distribution
  * Rank 0 quantizes once; the packed blob (header + fp32 layer 0 + int8 layers +
  * per-node offsets + biases + shift/scale + LUT) is broadcast over RCCL by the

@@ -92,3 +92,16 @@ def test_blob_check_rejects_garbage(tiny_model_path):
         api.host_blob_check(bad)
     with pytest.raises(api.FdnnError):
         api.host_blob_check(blob[:-256])
+
+
+def test_c_abi_shards_equal_the_python_shards():
+    """fdnn_group_shard (host C++, one process / N devices) and dist.frame_shards (one process per
+    GPU) cut a batch the same way: contiguous, sizes differing by at most one, covering [0, n)."""
+    from fast_dnn_amd import api
+    from fast_dnn_amd.dist import frame_shards
+
+    for n in (0, 1, 7, 8, 9, 1000, 10000, 1_000_000):
+        for world in (1, 2, 3, 8):
+            got = [api.group_shard(n, world, r) for r in range(world)]
+            assert got == frame_shards(n, world), (n, world)
+            assert got[0][0] == 0 and got[-1][1] == n
