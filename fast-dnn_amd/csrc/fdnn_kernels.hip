@@ -5,6 +5,9 @@
 #include "fdnn_device.hpp"
 #include "fdnn_kernels.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace fdnn {
 namespace {
 
@@ -13,10 +16,8 @@ namespace {
 // sum of the output kernel's per-64-node partials in a fixed order.
 // dst == out scales in place; the per-frame lazy call passes a host-mapped dst instead, so the
 // probabilities land in the caller's pinned buffer without a copy command.
-__global__ __launch_bounds__(256) void normalize_kernel(const float *out, float *dst, const float *partial, int n, int partial_ld,
-                                                        int rows, int n_partial) {
-  __shared__ float red[4];
-  const int f = blockIdx.x;
+__device__ __forceinline__ void normalize_row(const float *out, float *dst, const float *partial, int f, int partial_ld, int rows,
+                                              int n_partial, float *red) {
   const int tid = threadIdx.x;
   float s = 0.0f;
   for (int t = tid; t < n_partial; t += 256) s += partial[static_cast<size_t>(t) * partial_ld + f];
@@ -25,6 +26,12 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float *out, float 
   if ((tid & 63) == 0) red[tid >> 6] = s;
   __syncthreads();
   const float total = (red[0] + red[1]) + (red[2] + red[3]);
+  // p_i = e_i / total (dnn.cc:541-543) as e_i * RN(1 / total): within one ulp of the quotient
+  // (1.2e-7 relative; the hardware exp already differs from glibc's expf by more), and one
+  // multiply per element instead of the ~10-instruction IEEE division sequence -- which does not
+  // matter to this HBM-bound pass on its own, but is vector-ALU work taken from the next batch's
+  // layer 0 when the pass runs underneath it (server loop).
+  const float inv = 1.0f / total;
   const float *row = out + static_cast<size_t>(f) * rows;
   float *drow = dst + static_cast<size_t>(f) * rows;
   // Rows of any width (pdf counts are arbitrary): when rows % 4 != 0 a row starts off the 16-byte
@@ -44,19 +51,40 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float *out, float 
     const int groups = (rows - head) >> 2, tail0 = head + 4 * groups;
     for (int i = tid; i < groups; i += 256) {
       float4 v = r4[i];
-      v.x = v.x / total;
-      v.y = v.y / total;
-      v.z = v.z / total;
-      v.w = v.w / total;
+      v.x = v.x * inv;
+      v.y = v.y * inv;
+      v.z = v.z * inv;
+      v.w = v.w * inv;
       if ((FDNN_WT & 32) && wt_rows)
         store_wt(d4 + i, v4f_t{v.x, v.y, v.z, v.w});
       else
         d4[i] = v;
     }
-    if (tid < head) drow[tid] = row[tid] / total;
-    if (tid >= 64 && tid - 64 < rows - tail0) drow[tail0 + tid - 64] = row[tail0 + tid - 64] / total;
+    if (tid < head) drow[tid] = row[tid] * inv;
+    if (tid >= 64 && tid - 64 < rows - tail0) drow[tail0 + tid - 64] = row[tail0 + tid - 64] * inv;
   } else {
-    for (int i = tid; i < rows; i += 256) drow[i] = row[i] / total;
+    for (int i = tid; i < rows; i += 256) drow[i] = row[i] * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void normalize_kernel(const float *out, float *dst, const float *partial, int n, int partial_ld,
+                                                        int rows, int n_partial) {
+  __shared__ float red[4];
+  normalize_row(out, dst, partial, blockIdx.x, partial_ld, rows, n_partial, red);
+}
+
+// The same pass as a BACKGROUND kernel for the server loop: a fixed, small grid of workgroups that
+// walk the rows, so that it holds one or two wave slots per SIMD for its whole life instead of
+// flooding every CU with thousands of short workgroups.  Launched on the low-priority tail stream
+// under the next batch's layer 0, whose 228-register waves need the rest of the register file: with
+// the one-workgroup-per-row grid the short workgroups grabbed every slot that came free and layer 0
+// starved until the scale pass was done (rocprofv3 timeline: 120 us overlap, layer 0 330 -> 430 us).
+__global__ __launch_bounds__(256) void normalize_bg_kernel(const float *out, float *dst, const float *partial, int n,
+                                                           int partial_ld, int rows, int n_partial) {
+  __shared__ float red[4];
+  for (int f = blockIdx.x; f < n; f += gridDim.x) {
+    normalize_row(out, dst, partial, f, partial_ld, rows, n_partial, red);
+    __syncthreads();  // red[] is reused by the next row
   }
 }
 
@@ -151,8 +179,17 @@ __global__ __launch_bounds__(256) void xor80_kernel(const int8_t *in, uint8_t *o
 
 }  // namespace
 
-void launch_normalize(float *out, float *dst, const float *partial, int n, int partial_ld, int rows, int n_partial, hipStream_t s) {
+void launch_normalize(float *out, float *dst, const float *partial, int n, int partial_ld, int rows, int n_partial, hipStream_t s,
+                      bool background) {
   if (n <= 0) return;
+  if (background) {
+    static const int wgs = [] {
+      const char *e = std::getenv("FDNN_NORM_BG_WGS");
+      return e ? std::max(1, std::atoi(e)) : 512;
+    }();
+    hipLaunchKernelGGL(normalize_bg_kernel, dim3(std::min(n, wgs)), dim3(256), 0, s, out, dst, partial, n, partial_ld, rows, n_partial);
+    return;
+  }
   hipLaunchKernelGGL(normalize_kernel, dim3(n), dim3(256), 0, s, out, dst, partial, n, partial_ld, rows, n_partial);
 }
 

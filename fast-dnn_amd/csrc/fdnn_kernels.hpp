@@ -89,7 +89,9 @@ struct LazyFrameParams {
 void launch_lazy_frame(const LazyFrameParams &p, hipStream_t s);
 
 // dst[f][:] = out[f][:] / sum_t partial[t][f]   (dst == out: in place; dst may be host-mapped)
-void launch_normalize(float *out, float *dst, const float *partial, int n, int partial_ld, int rows, int n_partial, hipStream_t s);
+// background: a small fixed grid walking the rows (server loop: runs under the next batch's layer 0)
+void launch_normalize(float *out, float *dst, const float *partial, int n, int partial_ld, int rows, int n_partial, hipStream_t s,
+                      bool background = false);
 
 // Exhaustive check of the 3-op division against IEEE division for every int32
 // accumulator in [-2^26, 2^26]; *d_mismatch receives the count.

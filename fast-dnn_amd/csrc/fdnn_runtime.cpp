@@ -321,7 +321,8 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   }
   {
     ProfScope ps(m, ns, FDNN_PROF_NORMALIZE);
-    fdnn::launch_normalize(d_out, d_final ? d_final : d_out, c->d_partial, count, g.partial_ld, d.rows, d.rows_pad / fdnn::kPartialNodes, ns);
+    fdnn::launch_normalize(d_out, d_final ? d_final : d_out, c->d_partial, count, g.partial_ld, d.rows, d.rows_pad / fdnn::kPartialNodes, ns,
+                           ns != s);
   }
   HIP_TRY(hipGetLastError());
   return FDNN_OK;

@@ -290,10 +290,24 @@ void finisher_loop(fdnn_server *s) {
     Slot &sl = s->slots[size_t(si)];
     const hipError_t e = hipEventSynchronize(sl.done);
     const int status = e == hipSuccess ? FDNN_OK : FDNN_E_DEVICE;
-    for (const Piece &p : sl.pieces) {
-      if (!status) std::memcpy(p.out, sl.h_out + size_t(p.row0) * O, sizeof(float) * size_t(p.rows) * O);
-      if (p.last || status) complete_ticket(s, p.ticket, status);
+    if (!status) {
+      // hand the rows back: 32 KB per frame, so a full batch is hundreds of MB -- one thread's
+      // memcpy (~10 GB/s) would be the slowest stage of the loop; a few helpers share the pieces
+      const size_t total = sizeof(float) * size_t(sl.frames) * O;
+      const int helpers = total > (size_t(8) << 20) ? int(std::min<size_t>(6, sl.pieces.size())) : 1;
+      auto copy_share = [&](int t) {
+        for (size_t i = size_t(t); i < sl.pieces.size(); i += size_t(helpers)) {
+          const Piece &p = sl.pieces[i];
+          std::memcpy(p.out, sl.h_out + size_t(p.row0) * O, sizeof(float) * size_t(p.rows) * O);
+        }
+      };
+      std::vector<std::thread> pool;
+      for (int t = 1; t < helpers; ++t) pool.emplace_back(copy_share, t);
+      copy_share(0);
+      for (auto &th : pool) th.join();
     }
+    for (const Piece &p : sl.pieces)
+      if (p.last || status) complete_ticket(s, p.ticket, status);
     {
       std::lock_guard<std::mutex> lk(s->qmu);
       sl.in_flight = false;
@@ -328,8 +342,12 @@ int fdnn_server_create(fdnn_model *m, int max_frames, int depth, fdnn_server **o
   s->max_frames = max_frames;
   s->depth = depth;
   s->slots.resize(size_t(depth));
-  hipError_t e = hipStreamCreateWithFlags(&s->s_main, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->s_tail, hipStreamNonBlocking);
+  // the compute stream outranks the tail stream: when layer 0 of batch i+1 and the scale pass of
+  // batch i are both runnable, the dispatcher must place layer 0's big workgroups first
+  int prio_least = 0, prio_greatest = 0;
+  hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  hipError_t e = hipStreamCreateWithPriority(&s->s_main, hipStreamNonBlocking, prio_greatest);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&s->s_tail, hipStreamNonBlocking, prio_least);
   int rc = FDNN_OK;
   for (Slot &sl : s->slots) {
     if (e != hipSuccess || rc) break;

@@ -1,0 +1,86 @@
+// serve_bench -- the serving shape, natively: T host threads, each scoring U utterances of F frames
+// (100 frames = 1 s of speech) through the C-ABI, buffers reused, no interpreter in the loop.
+//   serve_bench model.bin threads utts_per_thread frames mode [max_frames depth linger_us]
+//   mode: percall  = fdnn_calculate per utterance (what the JNI calculate() does)
+//         server   = fdnn_server_submit + fdnn_server_wait (coalesced host submissions)
+//         batcher  = fdnn_calculate on a model with fdnn_model_enable_batcher
+// Prints one JSON line.  Build: see tools/serve_bench.sh.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../include/fdnn.h"
+
+int main(int argc, char **argv) {
+  if (argc < 6) {
+    std::fprintf(stderr, "usage: serve_bench model threads utts frames percall|server|batcher [max_frames depth linger_us]\n");
+    return 2;
+  }
+  const char *path = argv[1];
+  const int T = std::atoi(argv[2]), U = std::atoi(argv[3]), F = std::atoi(argv[4]);
+  const std::string mode = argv[5];
+  const int max_frames = argc > 6 ? std::atoi(argv[6]) : 6400, depth = argc > 7 ? std::atoi(argv[7]) : 3,
+            linger = argc > 8 ? std::atoi(argv[8]) : 100;
+  fdnn_model *m = nullptr;
+  if (fdnn_model_load(path, 3.0f, &m)) {
+    std::fprintf(stderr, "load: %s\n", fdnn_last_error());
+    return 1;
+  }
+  const int D = fdnn_model_input_dim(m), O = fdnn_model_output_dim(m);
+  fdnn_server *srv = nullptr;
+  if (mode == "server" && fdnn_server_create(m, max_frames, depth, &srv)) {
+    std::fprintf(stderr, "server: %s\n", fdnn_last_error());
+    return 1;
+  }
+  if (srv) fdnn_server_set_linger_us(srv, linger);
+  if (mode == "batcher" && fdnn_model_enable_batcher(m, max_frames, depth, linger)) {
+    std::fprintf(stderr, "batcher: %s\n", fdnn_last_error());
+    return 1;
+  }
+  std::vector<std::vector<float>> xs(static_cast<size_t>(T)), outs(static_cast<size_t>(T));
+  std::mt19937 rng(7);
+  std::normal_distribution<float> nd(0.0f, 15.0f);
+  for (int t = 0; t < T; ++t) {
+    xs[size_t(t)].resize(size_t(F) * D);
+    for (float &v : xs[size_t(t)]) v = nd(rng);
+    outs[size_t(t)].assign(size_t(F) * O, 0.0f);  // resident, like a reused JVM float[]
+  }
+  int failed = 0;
+  auto body = [&](int t, int utts) {
+    for (int u = 0; u < utts; ++u) {
+      int rc;
+      if (srv) {
+        uint64_t ticket = 0;
+        rc = fdnn_server_submit(srv, xs[size_t(t)].data(), F, nullptr, outs[size_t(t)].data(), &ticket);
+        if (!rc) rc = fdnn_server_wait(srv, ticket);
+      } else {
+        rc = fdnn_calculate(m, xs[size_t(t)].data(), F, D, 10, outs[size_t(t)].data());
+      }
+      if (rc) ++failed;
+    }
+  };
+  auto run = [&](int utts) {
+    std::vector<std::thread> th;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < T; ++t) th.emplace_back(body, t, utts);
+    for (auto &x : th) x.join();
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  };
+  run(std::max(2, U / 10));  // warm-up: contexts, pinned staging, clocks
+  const double sec = run(U);
+  double sum = 0.0;
+  for (int i = 0; i < O; ++i) sum += outs[0][size_t(i)];
+  uint64_t batches = 0, frames = 0, reqs = 0, coal = 0;
+  if (srv) fdnn_server_stats(srv, &batches, &frames, &reqs, &coal);
+  std::printf("{\"mode\": \"%s\", \"threads\": %d, \"frames_per_utt\": %d, \"utts\": %d, \"seconds\": %.4f, \"utts_per_s\": %.1f, "
+              "\"frames_per_s\": %.1f, \"row0_sum\": %.6f, \"failed\": %d, \"batches\": %llu, \"requests\": %llu}\n",
+              mode.c_str(), T, F, T * U, sec, T * U / sec, double(T) * U * F / sec, sum, failed, (unsigned long long)batches,
+              (unsigned long long)reqs);
+  if (srv) fdnn_server_free(srv);
+  fdnn_model_free(m);
+  return failed ? 1 : 0;
+}
