@@ -14,8 +14,10 @@ produce the files the native half reads:
 The ``.bin`` writers themselves live in ``formats.py``.  No JDK exists in this image, so the
 Java code cannot be run here: the feature-text path is pinned byte-for-byte against the
 reference's own ``data/16khz`` -> ``data/16khz.bin`` and ``data/8khz`` -> ``data/8khz.aligned.bin``
-pairs (tests/test_convert.py); the nnet-text parser has no reference fixture (no Kaldi text model
-ships with the reference) and is pinned only by restating the Java parser -- "parity unpinned".
+pairs (tests/test_convert.py).  No Kaldi text model ships with the reference, so the nnet-text
+parser, ``align`` and ``extend`` are pinned by a hand-derived fixture instead: a toy text net whose
+expected ``.bin`` bytes were laid out by hand from the Java source, independent of this module
+(tests/golden/make_kaldi_toy.py -> tests/golden/kaldi_toy/).
 
 Reference quirks kept on purpose (they shape the files real users have):
 
@@ -38,8 +40,33 @@ _BLOCK = re.compile(r"\[(.+?)\]", re.DOTALL)
 _ID = re.compile(r"(.+?)(?:\[.+?\])", re.DOTALL)
 
 
+def _parse_f32(tokens) -> np.ndarray:
+    """``Float.parseFloat`` of every token: the decimal correctly rounded to float32.  Going through
+    a double (strtod, then a cast) rounds twice; the two differ only when the double lands exactly
+    on a float32 rounding boundary (low 29 mantissa bits = 1000...0), so just those tokens -- about
+    one in 2^29 -- are settled with exact rational arithmetic."""
+    d = np.array([float(t) for t in tokens], dtype=np.float64)
+    f = d.astype(np.float32)
+    if d.size:
+        bits = d.view(np.uint64)
+        tie = np.flatnonzero(((bits & np.uint64(0x1FFFFFFF)) == np.uint64(0x10000000)) & np.isfinite(d) & (np.abs(d) >= 1.2e-38))
+        if tie.size:
+            from fractions import Fraction
+
+            for i in tie:
+                exact = Fraction(tokens[i])
+                lo = np.nextafter(np.float32(d[i]), np.float32(-np.inf)) if np.float32(d[i]) > d[i] else np.float32(d[i])
+                cands = [lo, np.nextafter(lo, np.float32(np.inf))]
+                err = [abs(Fraction(float(c)) - exact) for c in cands]
+                if err[0] != err[1]:
+                    f[i] = cands[0] if err[0] < err[1] else cands[1]
+                else:  # a true tie in the decimal itself: to even
+                    f[i] = cands[0] if (cands[0].view(np.uint32) & 1) == 0 else cands[1]
+    return f
+
+
 def _floats(text: str) -> np.ndarray:
-    return np.array([float(t) for t in text.split()], dtype=np.float32)
+    return _parse_f32(text.split())
 
 
 # ----------------------------------------------------------------------------- model text
@@ -71,7 +98,7 @@ def load_kaldi_layers_text(path: str) -> List[FloatLayerSpec]:
             want = in_count if i < node_count else node_count
             if len(vals) < want:
                 raise ValueError(f"{path}: layer {len(layers)} row {i} has {len(vals)} values, expected {want}")
-            rows.append(np.array([float(v) for v in vals[:want]], dtype=np.float32))
+            rows.append(_parse_f32(vals[:want]))
         layers.append(FloatLayerSpec(np.stack(rows[:node_count]), rows[node_count]))
     if not layers:
         raise ValueError(f"{path}: no <AffineTransform> layer found")
@@ -138,6 +165,8 @@ def _extend_vec(v: np.ndarray, size: int) -> np.ndarray:
 
 
 def _extend_layer(l: FloatLayerSpec, in_count: int, out_count: int) -> FloatLayerSpec:
+    if out_count < l.out_dim:  # Layer.extend indexes newWeights[i] for every existing node: Java throws here
+        raise ValueError(f"extend cannot shrink a layer from {l.out_dim} to {out_count} nodes")
     rows = l.weights[:, np.arange(in_count) % l.in_dim]          # every existing row, circular in k
     w = rows[np.arange(out_count) % l.out_dim].astype(np.float32)  # new nodes copy node i % out_dim
     return FloatLayerSpec(np.ascontiguousarray(w), _extend_vec(l.bias, out_count))

@@ -253,6 +253,26 @@ def generate_masks(count: int, dimension: int, ratio: float = 0.40, churn: float
     return res
 
 
+def generate_masks_fast(count: int, dimension: int, ratio: float = 0.40, churn: float = 0.03, seed: int = 11) -> np.ndarray:
+    """Masks with the statistics of ``generate_masks`` (FuncTest.java:121-154: ``ratio`` of the
+    nodes active, ``churn * dimension`` nodes switched on and as many switched off per frame) from a
+    per-node two-state Markov chain -- P(off -> on) = churn / (1 - ratio), P(on -> off) =
+    churn / ratio, stationary share ``ratio`` -- which vectorises over the nodes.  The active count
+    fluctuates around ``ratio * dimension`` instead of being pinned to it; for benchmarks, where
+    10 000 x 8000 masks must not take 20 s of rejection sampling (callers count the active nodes)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    p_on, p_off = churn / (1.0 - ratio), churn / ratio
+    res = np.empty((count, dimension), dtype=np.int8)
+    row = np.zeros(dimension, dtype=bool)
+    row[rng.choice(dimension, int(dimension * ratio), replace=False)] = True
+    for i in range(count):
+        if i:
+            u = rng.random(dimension, dtype=np.float32)
+            row = np.where(row, u >= p_off, u < p_on)
+        res[i] = row
+    return res
+
+
 def sha256_file(path: str) -> str:
     h = hashlib.sha256()
     with open(path, "rb") as f:

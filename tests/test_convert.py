@@ -145,3 +145,43 @@ def test_float_reference_and_quantization_report(tiny_model_path):
     rep = CV.quantization_report(ref, q)
     assert rep["frames"] == 100 and rep["nodes"] == 100
     assert rep["max_abs_diff"] < 0.05 and rep["top1_agreement"] > 0.9, rep
+
+
+TOY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kaldi_toy")
+
+
+def test_kaldi_text_to_bin_matches_the_hand_derived_bytes(tmp_path):
+    """f1 pin (no JDK here): tests/golden/make_kaldi_toy.py lays the expected files out by hand from
+    FeedForwardNetwork.java:50-66, :86-119, :159-207, :226-235, :262-302 -- <Splice> block dropped,
+    align(4, 16), extend(5, 4) with its zero-ALIGNED output layer, big-endian saveBinary -- without
+    touching fast_dnn_amd.convert.  The converter must reproduce them byte for byte."""
+    net = CV.load_kaldi_nnet_text(os.path.join(TOY, "final.nnet.txt"), os.path.join(TOY, "final.feature_transform.txt"))
+    assert [l.weights.shape for l in net.layers] == [(2, 3), (2, 2), (3, 2)]
+    p = str(tmp_path / "aligned.bin")
+    F.write_model_bin(p, CV.align(net, 4, 16))
+    assert open(p, "rb").read() == open(os.path.join(TOY, "aligned_4_16.bin"), "rb").read()
+    p = str(tmp_path / "extended.bin")
+    F.write_model_bin(p, CV.extend(net, 5, 4))
+    assert open(p, "rb").read() == open(os.path.join(TOY, "extended_5_4.bin"), "rb").read()
+    with pytest.raises(ValueError):
+        CV.extend(net, 1, 4)  # Layer.extend cannot shrink (ArrayIndexOutOfBounds in the reference)
+    # and the fixture really is what the generator writes (it is committed, not regenerated in CI)
+    import subprocess
+    import sys
+
+    gen = os.path.join(os.path.dirname(TOY), "make_kaldi_toy.py")
+    before = {f: open(os.path.join(TOY, f), "rb").read() for f in os.listdir(TOY)}
+    subprocess.check_call([sys.executable, gen], stdout=subprocess.DEVNULL)
+    assert before == {f: open(os.path.join(TOY, f), "rb").read() for f in os.listdir(TOY)}
+
+
+def test_decimal_tokens_round_once_like_float_parsefloat():
+    """Float.parseFloat rounds the decimal to float32 ONCE; strtod-then-cast rounds twice and is
+    wrong when the double lands exactly on a float32 boundary."""
+    # 1 + 2^-24 + 2^-60: just above the midpoint of 1.0 and 1.0 + 2^-23 -> must round UP; as a double it IS the midpoint (-> even = 1.0)
+    tok = "1.00000005960464477626025342456"
+    assert float(tok) == 1.0 + 2.0 ** -24 and np.float32(float(tok)) == np.float32(1.0)
+    got = CV._parse_f32([tok, "0.1", "-7.5e-2", "1.000000059604644775390625"])  # the last one IS the exact tie -> even
+    assert got[0] == np.nextafter(np.float32(1.0), np.float32(2.0))
+    assert got[1].view(np.uint32) == 0x3DCCCCCD and got[2].view(np.uint32) == 0xBD99999A
+    assert got[3] == np.float32(1.0)

@@ -522,3 +522,31 @@ def test_output_widths_not_multiple_of_four(tmp_models, out_dim):
     assert np.array_equal(ctx.calculateForOutputNodes(masks[5]), got[5])
     ctx.delete()
     dnn.delete()
+
+
+def test_kaldi_text_model_through_the_hip_path(tmp_path):
+    """SURVEY 8(f) row 1 end to end: Kaldi nnet1 text + feature_transform (with a <Splice> block)
+    -> convert.load_kaldi_nnet_text -> align(4, 16) -> .bin (FuncTest.java:20-28, the reference's
+    own preparation recipe) -> scored by the HIP path == the oracle on the same file."""
+    from fast_dnn_amd import convert as CV
+    from test_convert import _kaldi_text, _transform_text
+
+    net = F.synth_net([39, 21, 21, 21, 13], seed=5)  # unaligned on purpose: 39 -> 40 inputs, 21 -> 32 hidden nodes
+    (tmp_path / "final.nnet.txt").write_text(_kaldi_text(net), encoding="utf-8")
+    (tmp_path / "final.feature_transform.txt").write_text(_transform_text(net.shift, net.scale, True), encoding="utf-8")
+    got = CV.load_kaldi_nnet_text(str(tmp_path / "final.nnet.txt"), str(tmp_path / "final.feature_transform.txt"))
+    p = str(tmp_path / "model.bin")
+    F.write_model_bin(p, CV.align(got, 4, 16))
+    x = CV.align_features(F.synth_features(150, 39, seed=3, pad_from=None), 4)
+    want, wt = Oracle(p).calculate(x, taps=True)
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    assert (dnn.inputDimension(), dnn.hiddenDimension(), dnn.outputDimension()) == (40, 32, 13)
+    t = dnn.forwardTaps(x)
+    assert (t["u8_acts"] == wt["u8_acts"]).all()
+    assert (t["acc_hid"] == wt["acc_hid"]).all() and (t["acc_out"] == wt["acc_out"]).all()
+    assert np.abs(t["probs"] - want).max() <= TIGHT
+    # the padded hidden nodes have zero weights and zero bias: sigmoid(0) -> table entry 128, fed to zero columns
+    assert (t["u8_acts"][:, :, 21:] == 128).all()
+    ref = CV.float_forward(CV.align(got, 4, 16), x)
+    assert CV.quantization_report(ref, dnn.calculate(x))["max_abs_diff"] < 0.1
+    dnn.delete()
