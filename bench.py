@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
 """bench.py -- acoustic frames/s of the quantized scorer on 1..N MI355X.
 
-A "step" is one pass of the whole hot path (QuantizedDnn.calculate: shift/scale,
-fp32 layer 0, six int8 2048x2048 layers, int8 8000x2048 output layer, soft-max)
-over one 10 000-frame batch per GPU of the synthetic 7x2048 -> 8000 net
-(BASELINE.json configs[2]; configs[1]'s "model" file is a feature batch, see
-SURVEY.md section 0).  Inputs and outputs are device resident; the weights are
-quantized once on rank 0 and broadcast over RCCL at load time only; there is no
-collective in the timed region (frames are independent: weak scaling).
+A "step" is one pass of the whole hot path (QuantizedDnn.calculate: shift/scale, fp32 layer 0,
+six int8 2048x2048 layers, int8 8000x2048 output layer, soft-max) over one 10 000-frame batch per
+GPU of the synthetic 7x2048 -> 8000 net (BASELINE.json configs[2]; configs[1]'s "model" file is a
+feature batch).  Inputs and outputs are device resident; the weights are
+quantized once on rank 0 and broadcast over RCCL at load time only; there is no collective in the
+timed region (frames are independent: weak scaling).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (contract in the task statement) including
-`roofline` for the dominant kernel class (the int8 hidden-layer GEMM, measured with
-HIP events on its launch stream in a second pass over the same K steps) and
-`cpu_baseline` (the SSE4.1 oracle port timed on this host, N=1 only).  Setup (model load,
-0.5 s of untimed forward passes that bring a cold device to its sustained clocks, reported as
-`setup.clock_ramp_steps`) comes before the W warm-up steps; the timed region is exactly K steps.
+The K timed steps are submitted to the scoring loop (fdnn_server_*, in-flight depth 2: the
+HBM-bound soft-max scale of step i runs under the VALU-bound layer 0 of step i+1, every step a
+complete pass with its own output buffer) and the clock stops when the last result is complete.
+The same K steps back to back on one stream (fdnn_calculate_device) are reported as `single_stream`.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with
+  roofline             the kernel class with the largest share of the step, live HIP-event times
+  roofline_kernels     all four classes (layer 0, hidden int8 GEMM, output int8 GEMM, soft-max scale)
+  roofline_int8_gemm   the hidden-layer int8 GEMM by name (the MFMA kernel the net is made of)
+  end_to_end           value against the int8-MFMA ceiling of the whole net (60 M frames/s)
+  lazy_40pct           BASELINE configs[3]: LazyContext contract, 40 % mask with 3 % churn, same batch
+  cpu_baseline         the reference algorithm (oracle SSE4.1 port) on this host's cores, N=1 only
+Setup (model load, 0.5 s of untimed passes that bring a cold device to its sustained clocks,
+reported as `setup.clock_ramp_steps`) comes before the W warm-up steps.
 """
 import argparse
 import json
@@ -32,55 +39,120 @@ import numpy as np  # noqa: E402
 
 FRAMES_PER_GPU = 10000
 INT8_PEAK_TOPS = 5000.0  # dense int8 MFMA, 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
-HIDDEN_OPS_PER_FRAME = 2 * 2048 * 2048  # one hidden layer, int8 ops
+FP32_NOFMA_TFLOPS = 78.65  # fp32 vector peak 157.3 counts an fma as two; multiply and add rounded separately -> half
+HBM_PEAK_GBS = 8000.0
 INT8_OPS_PER_FRAME = 83_099_648  # 6*2048^2 + 8000*2048 MAC, x2
+INT8_OPS_HIDDEN_LAYERS = 2 * 6 * 2048 * 2048
+ROOFLINE_FRAMES_PER_S = INT8_PEAK_TOPS * 1e12 / INT8_OPS_PER_FRAME  # 60.2 M frames/s
 
 
-def cpu_baseline(model_path: str, sample_utts: int = 4, frames: int = 100):
-    """The reference algorithm (oracle SSE4.1 port, frame-block 8) on this host:
-    one thread, then one context per thread on independent 100-frame utterances
-    (the reference's own concurrency model, MultiThreadedStressTest.java:48-61)."""
-    from concurrent.futures import ThreadPoolExecutor
+def host_info() -> dict:
+    """CPU model, physical cores, logical CPUs this process may use, cgroup CPU quota."""
+    info = {"logical_cpus": len(os.sched_getaffinity(0))}
+    try:
+        model, cores = None, set()
+        phys = core = None
+        allowed = os.sched_getaffinity(0)
+        cpu = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                cpu = int(v)
+            elif k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and cpu is not None:
+                if cpu in allowed and phys is not None:
+                    cores.add((phys, core))
+                phys = core = cpu = None
+        info["cpu_model"] = model
+        info["physical_cores"] = len(cores) or None
+    except OSError:
+        pass
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota = None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                quota = None if q < 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            info["cgroup_cpu_quota"] = quota
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return info
+
+
+def cpu_baseline(model_path: str, frames: int = 100) -> dict:
+    """The reference algorithm (oracle SSE4.1 port, frame-block 8) on this host: a native pthread
+    harness (oracle/fdnn_oracle.c: orc_bench_threads), no interpreter in the timed region -- one
+    thread, then one thread per usable core, each scoring independent 100-frame utterances with a
+    private context per call (the reference's own concurrency model,
+    MultiThreadedStressTest.java:48-61; timed region as in the reference CLI, dnn.cc:64-71)."""
+    import ctypes as C
 
     from fast_dnn_amd import formats as F
     from oracle.oracle import Oracle
 
     orc = Oracle(model_path)
-    utts = [F.synth_features(frames, seed=900 + i) for i in range(8)]
-    orc.calculate(utts[0], batch=8, sse=True)  # warm-up
-    t = []
-    for i in range(sample_utts):
-        t0 = time.perf_counter()
-        orc.calculate(utts[i % len(utts)], batch=8, sse=True)
-        t.append(time.perf_counter() - t0)
-    one = frames / float(np.median(t))
-    cores = len(os.sched_getaffinity(0))
-    threads = max(1, cores)
-    per_thread = 2
-    with ThreadPoolExecutor(threads) as ex:
-        t0 = time.perf_counter()
-        list(ex.map(lambda i: orc.calculate(utts[i % len(utts)], batch=8, sse=True), range(threads * per_thread)))
-        dt = time.perf_counter() - t0
-    many = threads * per_thread * frames / dt
+    L = Oracle.lib()
+    L.orc_bench_threads.restype = C.c_double
+    L.orc_bench_threads.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    x = F.synth_features(frames, seed=900)
+    xp = x.ctypes.data_as(C.POINTER(C.c_float))
+
+    def run(threads, utts):
+        per = (C.c_double * threads)()
+        wall = L.orc_bench_threads(orc.h, xp, frames, 8, 1, threads, utts, per)
+        if wall <= 0:
+            raise RuntimeError("oracle thread harness failed")
+        return wall, list(per)
+
+    run(1, 1)  # warm-up
+    one = float(np.median([frames / run(1, 1)[0] for _ in range(3)]))
+    host = host_info()
+    usable = host.get("physical_cores") or host["logical_cpus"]
+    if host.get("cgroup_cpu_quota"):
+        usable = max(1, min(usable, int(host["cgroup_cpu_quota"])))
+    usable = min(usable, host["logical_cpus"])
+    utts = 2
+    wall, per = run(usable, utts)
+    many = usable * utts * frames / wall
     return {
-        "value": round(many, 1), "unit": "frames/s", "cores": threads, "kind": "port",
+        "value": round(many, 1), "unit": "frames/s", "cores": usable, "kind": "port",
         "value_1thread": round(one, 1),
-        "sample": f"oracle SSE4.1 port (pmaddubsw, frame-block 8) of the same net: {sample_utts} x {frames}-frame utterances "
-                  f"on 1 thread (median), then {threads * per_thread} utterances on {threads} threads, one context each",
+        "scaling_vs_1thread": round(many / one, 2),
+        "slowest_thread_s": round(max(per), 3), "fastest_thread_s": round(min(per), 3),
+        "host": host,
+        "sample": f"oracle SSE4.1 port (pmaddubsw, frame-block 8) of the same net, native pthread harness: 3 x {frames}-frame "
+                  f"utterances on 1 thread (median), then {usable * utts} utterances on {usable} threads (one per physical core "
+                  f"within the cgroup quota), one context per call; every thread streams the 45 MB of weights once per 8-frame "
+                  f"block, so the multi-thread figure is bound by shared cache / memory bandwidth, not by core count",
     }
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: ~0.25 s of GPU time per pass; short runs (20 steps) read ~6 % low because the
-    # clocks are still ramping when the timed region starts
+    # defaults: ~0.2 s of GPU time per pass; short runs (20 steps) read low without the clock ramp below
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU,
+                    help="frames per GPU per step (BASELINE configs[4] = 1 M frames over 8 GPUs: --gpus 8 --frames 125000)")
     ap.add_argument("--mode", default="gauss", choices=["gauss", "nosat"], help="synthetic weight distribution")
+    ap.add_argument("--in-flight", type=int, default=2, help="steps in flight in the scoring loop (1 = no overlap between steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-lazy", action="store_true", help="skip the configs[3] leg")
     ap.add_argument("--clock-ramp-s", type=float, default=0.5, help="seconds of untimed load before the W warm-up steps (setup)")
+    ap.add_argument("--single-stream-only", action="store_true",
+                    help="profiling runs (tools/profile_round.sh): only the back-to-back single-stream steps, so that rocprofv3's "
+                         "per-kernel averages are not mixed with the overlapped legs")
     ap.add_argument("--l0-fma", action="store_true",
                     help="layer 0 with the fused multiply-add numerics of a -march=native reference build (fp32 MFMA)")
     args = ap.parse_args()
@@ -113,15 +185,17 @@ def main() -> None:
     dnn = load_replicated(model_path, local, rank, world)
     O = dnn.outputDimension()
     n = args.frames
+    depth = max(1, args.in_flight)
     if args.l0_fma:
         dnn.setInputLayerFma(True)
 
     x = torch.from_numpy(F.synth_features(n, 432, seed=1000 + rank)).to(dev)
-    out = torch.empty((n, O), dtype=torch.float32, device=dev)
+    outs = [torch.empty((n, O), dtype=torch.float32, device=dev) for _ in range(depth)]
     stream = torch.cuda.current_stream()
+    srv = api.ScoringServer(dnn, n, depth)
 
-    def step():
-        dnn.calculate_device(x.data_ptr(), n, out.data_ptr(), stream.cuda_stream)
+    def step_single():
+        dnn.calculate_device(x.data_ptr(), n, outs[0].data_ptr(), stream.cuda_stream)
 
     def fence():
         if world > 1:
@@ -135,16 +209,38 @@ def main() -> None:
     ramp_t0 = time.perf_counter()
     while time.perf_counter() - ramp_t0 < args.clock_ramp_s:
         for _ in range(10):
-            step()
+            step_single()
         torch.cuda.synchronize()
         ramp_steps += 10
 
-    for _ in range(args.warmup):
-        step()
+    if args.single_stream_only:
+        for _ in range(args.warmup):
+            step_single()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_single()
+        fence()
+        el = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({"mode": "single-stream-only", "frames_per_s": round(world * n * args.steps / el, 1),
+                              "ms_per_step": round(el / args.steps * 1e3, 4), "steps": args.steps, "frames_per_gpu": n}), flush=True)
+        srv.close()
+        dnn.delete()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- the timed region: K complete passes through the scoring loop
+    for i in range(args.warmup):
+        srv.submit_device(x.data_ptr(), n, outs[i % depth].data_ptr())
+    srv.drain()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        srv.submit_device(x.data_ptr(), n, outs[i % depth].data_ptr())
+    srv.drain()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -152,56 +248,147 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # sanity on the last output: soft-max rows sum to one
-    row_sum = float(out[:64].sum(1).mean().item())
+    # sanity on the last outputs: soft-max rows sum to one, every in-flight buffer holds the same result
+    row_sum = float(outs[0][:64].sum(1).mean().item())
     if not os.environ.get("FDNN_BENCH_NOCHECK"):  # (set only for kernel-ablation timing builds)
         assert abs(row_sum - 1.0) < 1e-3, row_sum
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0]), "in-flight steps disagree"
 
-    # second pass over the same K steps with per-kernel HIP events (rank 0 reports)
+    # ---- the same K steps back to back on one stream
+    for _ in range(args.warmup):
+        step_single()
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step_single()
+    fence()
+    single_elapsed = time.perf_counter() - t1
+
+    # ---- per-kernel HIP events over the same K steps (single stream; rank 0 reports)
     dnn.profileBegin()
     for _ in range(args.steps):
-        step()
+        step_single()
     torch.cuda.synchronize()
     prof = dnn.profileEnd()
 
-    # third pass (rank 0, N=1 only, informational): the other layer-0 flavour on the same batch
+    # ---- the other layer-0 flavour (rank 0, N=1 only, informational)
     alt = None
     if world == 1:
         dnn.setInputLayerFma(not args.l0_fma)
         for _ in range(args.warmup):
-            step()
+            step_single()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        t2 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            step_single()
         torch.cuda.synchronize()
-        alt = n * args.steps / (time.perf_counter() - t1)
+        alt = n * args.steps / (time.perf_counter() - t2)
         dnn.setInputLayerFma(args.l0_fma)
 
+    # ---- BASELINE configs[3]: the lazy contract, 40 % of the output nodes active, 3 % churn per frame
+    lazy = None
+    if world == 1 and not args.no_lazy:
+        masks = F.generate_masks_fast(n, O, 0.40, 0.03, seed=11)
+        active = float(masks.mean())
+        md = torch.from_numpy(masks).to(dev)
+        k_lazy = max(10, args.steps // 4)
+        for i in range(args.warmup):
+            srv.submit_device(x.data_ptr(), n, outs[i % depth].data_ptr(), md.data_ptr())
+        srv.drain()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for i in range(k_lazy):
+            srv.submit_device(x.data_ptr(), n, outs[i % depth].data_ptr(), md.data_ptr())
+        srv.drain()
+        torch.cuda.synchronize()
+        lazy_s = (time.perf_counter() - t3) / k_lazy
+        off = md[:64] == 0
+        o64 = outs[(k_lazy - 1) % depth][:64]
+        lo = torch.where(off, o64, torch.full_like(o64, float("inf"))).min(1).values
+        hi = torch.where(off, o64, torch.full_like(o64, float("-inf"))).max(1).values
+        assert bool((lo == hi).all()), "masked-out nodes must all read 1/total"
+        masked_ops = INT8_OPS_HIDDEN_LAYERS + 2 * 2048 * O * active  # count masked work only
+        lazy = {
+            "workload": f"BASELINE configs[3]: same net and batch, LazyContext contract, masks with {active:.3f} of the {O} output "
+                        f"nodes active and 3 % churn per frame (FuncTest.java:121-133 statistics), masks device resident",
+            "frames_per_s": round(n / lazy_s, 1), "ms_per_step": round(lazy_s * 1e3, 4), "steps": k_lazy,
+            "int8_ops_per_frame_masked_work": int(masked_ops),
+            "int8_tops_masked_work": round(masked_ops * n / lazy_s / 1e12, 1),
+            "frac_of_int8_peak_masked_work": round(masked_ops * n / lazy_s / 1e12 / INT8_PEAK_TOPS, 4),
+            "note": "the output GEMM runs dense and masks in its epilogue: over a 320-frame tile the union of the per-frame "
+                    "masks covers ~all nodes (DESIGN.md, mask-union density), so row compaction has nothing to drop",
+        }
+        del md, masks
+
+    srv.close()
     if rank == 0:
-        # HBM-side bytes per launch of the dominant kernel come from the committed PMC passes
-        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as the
-        # gfx950 guide prescribes); bench.py itself cannot run under rocprof.
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
-            for name, c in pm.items():
-                if name.startswith("qgemm_kernel hidden") and n == FRAMES_PER_GPU:
-                    traffic = int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1000)  # bytes per launch
+        steps = args.steps
+        # HBM-side bytes per launch come from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes); bench.py
+        # itself cannot run under rocprof.  Newest round first.
+        pmc, pmc_file = {}, None
+        for cand in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                pmc_file = cand
+                break
+            except Exception:
+                continue
+
+        def traffic_of(prefix):
+            if n != FRAMES_PER_GPU:
+                return None
+            for name, c in pmc.items():
+                if name.startswith(prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1000)  # bytes per launch
+            return None
+
+        step_ms = elapsed / steps * 1e3
+        kinds = []
+
+        def add(key, kernel, bound, work_per_launch, peak, unit, scale, alg_bytes, pmc_prefix):
+            pr = prof[key]
+            if not pr["launches"]:
+                return
+            per_launch_ms = pr["ms"] / pr["launches"]
+            per_step_ms = pr["ms"] / steps
+            achieved = work_per_launch / (per_launch_ms * 1e-3) / scale
+            kinds.append({
+                "kernel": kernel, "bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
+                "frac": round(achieved / peak, 4), "traffic": traffic_of(pmc_prefix),
+                "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(per_launch_ms, 4),
+                "launches_per_step": pr["launches"] // steps, "ms_per_step": round(per_step_ms, 4),
+                "share_of_single_stream_step": round(per_step_ms / (single_elapsed / steps * 1e3), 4),
+            })
+
+        l0_peak = 157.3 if args.l0_fma else FP32_NOFMA_TFLOPS
+        add("l0", "layer 0: l0_image_kernel + " + ("l0_mfma_kernel (fused flavour, fp32 MFMA)" if args.l0_fma else
+            "l0_chain_kernel (canonical flavour: multiply and add rounded separately, so the vector pipe does two instructions per MAC and no fma)"),
+            "mfma" if args.l0_fma else "valu", 2.0 * 432 * 2048 * n, l0_peak, "TFLOP/s", 1e12,
+            4 * (432 * n + 432 * 2048) + 2048 * n, "l0_chain_kernel")
+        add("hidden_gemm", "qgemm_kernel<hidden> (int8 MFMA 32x32x32, 2048x2048 layer + dequant/bias/sigmoid-table epilogue)",
+            "mfma", 2.0 * 2048 * 2048 * n, INT8_PEAK_TOPS, "TOP/s", 1e12, 2048 * 2048 + 2 * n * 2048, "qgemm_kernel hidden")
+        add("output_gemm", "qgemm_kernel<output> (int8 MFMA, 8000x2048 layer + dequant/bias/exp epilogue, 32 KB of exp(z) per frame out)",
+            "mfma", 2.0 * 2048 * O * n, INT8_PEAK_TOPS, "TOP/s", 1e12, 2048 * O + n * 2048 + 4 * n * O, "qgemm_kernel output")
+        add("normalize", "normalize_kernel (soft-max scale: read + write [n][8000] fp32)", "hbm", 2.0 * O * 4 * n, HBM_PEAK_GBS,
+            "GB/s", 1e9, 2 * O * 4 * n, "normalize_kernel")
+        dominant = max(kinds, key=lambda k: k["ms_per_step"])
+        gemm = next(k for k in kinds if k["kernel"].startswith("qgemm_kernel<hidden>"))
+        rocprof = None
+        try:  # the same fractions from the committed rocprofv3 averages (tools/profile_round.sh)
+            rocprof = json.load(open(os.path.join(ROOT, "profiles", "r02_roofline.json")))
         except Exception:
-            traffic = None
-        hid = prof["hidden_gemm"]
-        hid_ms = hid["ms"] / max(hid["launches"], 1)
-        achieved = HIDDEN_OPS_PER_FRAME * n / (hid_ms * 1e-3) / 1e12
-        kernels_ms = {k: round(v["ms"] / args.steps, 4) for k, v in prof.items()}
+            pass
+        value = world * n * steps / elapsed
         res = {
             "metric": "acoustic frames/sec (whole node), 7x2048->8000 nnet",
-            "value": round(world * n * args.steps / elapsed, 1),
+            "value": round(value, 1),
             "unit": "frames/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(step_ms, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -212,36 +399,31 @@ def main() -> None:
                             f"{n}-frame batch per GPU, full soft-max, device-resident in/out",
                 "frames_per_gpu": n, "global_frames": world * n, "parallelism": f"frame-sharded x{world}, replicated weights",
                 "layer0_numerics": "fused (reference built -march=native)" if args.l0_fma else "unfused (reference built -msse4, canonical)",
+                "steps_in_flight": depth,
+                "submission": "fdnn_server_submit_device: every step a complete pass into its own output buffer; the soft-max "
+                              "scale of step i runs on a second stream under layer 0 of step i+1",
             },
-            "x_realtime_per_gpu": round(n * args.steps / elapsed / 100.0, 1),
-            "int8_tops_end_to_end": round(INT8_OPS_PER_FRAME * n * args.steps / elapsed / 1e12, 1),
-            "roofline": {
-                "kernel": "qgemm_kernel<hidden> (int8 MFMA 2048x2048 layer + dequant/bias/sigmoid-LUT epilogue)",
-                "bound": "mfma", "achieved": round(achieved, 1), "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
-                "frac": round(achieved / INT8_PEAK_TOPS, 4), "traffic": traffic,
-                "traffic_unit": "HBM+MALL bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_summary.json)",
-                "algorithmic_bytes_per_launch": 2048 * 2048 + 2 * n * 2048,
-                "avg_launch_ms": round(hid_ms, 4), "launches": hid["launches"],
-            },
+            "x_realtime_per_gpu": round(value / world / 100.0, 1),
+            "int8_tops_end_to_end": round(INT8_OPS_PER_FRAME * value / world / 1e12, 1),
+            "single_stream": {"frames_per_s": round(world * n * steps / single_elapsed, 1), "ms_per_step": round(single_elapsed / steps * 1e3, 4),
+                              "note": "the same K steps as back-to-back fdnn_calculate_device calls on one stream (no overlap between steps)"},
+            "roofline": dict(dominant, note="largest share of the step; times from HIP events on the launch stream, which add ~4 us per "
+                                            "bracketed launch -- profiles/r02_roofline.json holds the rocprofv3 averages"),
+            "roofline_int8_gemm": gemm,
+            "roofline_kernels": kinds,
+            "end_to_end": {"bound": "mfma", "achieved": round(value / world, 1), "peak": round(ROOFLINE_FRAMES_PER_S, 1), "unit": "frames/s per GPU",
+                           "frac": round(value / world / ROOFLINE_FRAMES_PER_S, 4),
+                           "note": "5 POP/s int8 / 83.1 M int8 ops per frame; layer 0 (2 % of the MACs, fp32, unfused) and the soft-max "
+                                   "write (32 KB per frame) are not int8-MFMA work and take 36 % + 11 % of the step"},
+            "traffic_source": pmc_file,
+            "rocprof": rocprof,
             "setup": {"clock_ramp_steps": ramp_steps, "clock_ramp_s": args.clock_ramp_s,
                       "note": "untimed forward passes before the W warm-up steps, so that short runs see sustained clocks"},
-            "kernel_ms_per_step": kernels_ms,
-            # the other two bounds of the step, same live HIP-event times: layer 0 against the packed
-            # fp32 vector rate WITHOUT fma (multiply and add round separately in the canonical
-            # numerics: 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz), the soft-max scale against HBM
-            "roofline_other": [
-                {"kernel": "layer 0 (l0_image_kernel + l0_chain_kernel; --l0-fma: l0_mfma_kernel on the fp32 MFMA, 157.3 peak)",
-                 "bound": "mfma" if args.l0_fma else "valu",
-                 "achieved": round(2 * 432 * 2048 * n / (prof["l0"]["ms"] / args.steps * 1e-3) / 1e12, 1),
-                 "peak": 157.3 if args.l0_fma else 78.6, "unit": "TFLOP/s",
-                 "frac": round(2 * 432 * 2048 * n / (prof["l0"]["ms"] / args.steps * 1e-3) / 1e12 / (157.3 if args.l0_fma else 78.6), 4)},
-                {"kernel": "normalize_kernel (soft-max scale: read + write [n][8000] fp32)", "bound": "hbm",
-                 "achieved": round(2 * 8000 * 4 * n / (prof["normalize"]["ms"] / args.steps * 1e-3) / 1e9, 1), "peak": 8000.0,
-                 "unit": "GB/s", "frac": round(2 * 8000 * 4 * n / (prof["normalize"]["ms"] / args.steps * 1e-3) / 1e9 / 8000.0, 4)},
-            ],
+            "kernel_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in prof.items()},
             "other_layer0_flavour": None if alt is None else {
                 "layer0_numerics": "unfused (canonical)" if args.l0_fma else "fused (reference built -march=native), fp32 MFMA",
-                "frames_per_s": round(alt, 1)},
+                "frames_per_s_single_stream": round(alt, 1)},
+            "lazy_40pct": lazy,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model_path)

@@ -12,7 +12,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
-BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 3"
+BENCH="python $ROOT/bench.py --single-stream-only --steps 40 --warmup 5"
 T="timeout -k 5 240"
 
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o k -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_stats.log
@@ -31,4 +31,5 @@ pass tcc TCC_HIT_sum TCC_MISS_sum
 python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_summary.json $OUT/prof_${TAG}_pmc_sq/p_counter_collection.csv \
   $OUT/prof_${TAG}_pmc_fetch/p_counter_collection.csv $OUT/prof_${TAG}_pmc_write/p_counter_collection.csv \
   $OUT/prof_${TAG}_pmc_tcc/p_counter_collection.csv
-head -6 $OUT/${TAG}_kernel_stats.csv
+python $ROOT/tools/roofline_from_rocprof.py $OUT/${TAG}_kernel_stats.csv $OUT/${TAG}_pmc_summary.json $OUT/${TAG}_roofline.json
+head -8 $OUT/${TAG}_kernel_stats.csv

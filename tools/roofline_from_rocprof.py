@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""profiles/rNN_roofline.json: the roofline fractions computed from rocprofv3's per-kernel average
+durations (kernel_stats.csv of `bench.py --single-stream-only`) -- the numbers bench.py's `roofline`
+objects must agree with (its own times come from HIP events, which add ~4 us per bracketed launch).
+
+    python tools/roofline_from_rocprof.py kernel_stats.csv pmc_summary.json out.json [frames]
+"""
+import csv
+import json
+import sys
+
+stats, pmc_path, out = sys.argv[1:4]
+n = int(sys.argv[4]) if len(sys.argv) > 4 else 10000
+O, H, D = 8000, 2048, 432
+try:
+    pmc = json.load(open(pmc_path))
+except Exception:
+    pmc = {}
+
+
+def traffic(prefix):
+    for name, c in pmc.items():
+        if name.startswith(prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1000)
+    return None
+
+
+rows = list(csv.DictReader(open(stats)))
+total_ns = sum(float(r["TotalDurationNs"]) for r in rows if "fdnn" in r["Name"] and "fastdiv" not in r["Name"] and "weight_image" not in r["Name"])
+res = {"source": stats.split("/")[-1], "frames": n, "kernels": []}
+for r in rows:
+    nm = r["Name"]
+    avg_us = float(r["AverageNs"]) / 1e3
+    if "qgemm_kernel" in nm:
+        args = nm.split("qgemm_kernel<")[1].split(">")[0].replace(" ", "").split(",")
+        output = args[4] == "true"
+        rows_l = O if output else H
+        ent = dict(kernel=f"qgemm_kernel<{'output' if output else 'hidden'}> {32 * int(args[0]) * int(args[1])}-frame tile", bound="mfma",
+                   achieved=round(2.0 * rows_l * H * n / (avg_us * 1e-6) / 1e12, 1), peak=5000.0, unit="TOP/s",
+                   algorithmic_bytes_per_launch=rows_l * H + n * H + (4 * n * O if output else n * H),
+                   traffic=traffic("qgemm_kernel output" if output else "qgemm_kernel hidden"))
+    elif "l0_chain_kernel" in nm:
+        ent = dict(kernel="l0_chain_kernel (fp32, multiply and add rounded separately)", bound="valu",
+                   achieved=round(2.0 * D * H * n / (avg_us * 1e-6) / 1e12, 1), peak=78.65, unit="TFLOP/s",
+                   algorithmic_bytes_per_launch=4 * (D * n + D * H) + H * n, traffic=traffic("l0_chain_kernel"))
+    elif "l0_image_kernel" in nm:
+        ent = dict(kernel="l0_image_kernel (shift/scale + chain-major transpose of the frames)", bound="hbm",
+                   achieved=round(2.0 * 4 * D * n / (avg_us * 1e-6) / 1e9, 1), peak=8000.0, unit="GB/s",
+                   algorithmic_bytes_per_launch=2 * 4 * D * n, traffic=traffic("l0_image_kernel"))
+    elif "normalize_kernel" in nm:
+        ent = dict(kernel="normalize_kernel (soft-max scale)", bound="hbm", achieved=round(2.0 * 4 * O * n / (avg_us * 1e-6) / 1e9, 1),
+                   peak=8000.0, unit="GB/s", algorithmic_bytes_per_launch=2 * 4 * O * n, traffic=traffic("normalize_kernel"))
+    else:
+        continue
+    ent.update(frac=round(ent["achieved"] / ent["peak"], 4), avg_launch_us=round(avg_us, 2), calls=int(r["Calls"]),
+               share_of_gpu_time=round(float(r["TotalDurationNs"]) / total_ns, 4))
+    res["kernels"].append(ent)
+res["kernels"].sort(key=lambda e: -e["share_of_gpu_time"])
+if res["kernels"]:
+    res["dominant"] = res["kernels"][0]["kernel"]
+step_us = sum(e["avg_launch_us"] * (6 if "hidden" in e["kernel"] else 1) for e in res["kernels"])
+res["sum_of_kernel_time_per_step_us"] = round(step_us, 1)
+res["end_to_end_frac_of_int8_roofline_from_kernel_time"] = round(n / (step_us * 1e-6) / (5000e12 / 83_099_648), 4)
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
