@@ -27,12 +27,13 @@ struct L0Params {
   // canonical flavour: chain-major operand images  img[(c + 2) % 4][j][col] = src[col][4j + c]
   float *xt;           // [4][j_pad][n_ld] frame image, scratch, rewritten by every launch
   const float *wt;     // [4][j_pad][h_ld] weight image (launch_l0_weight_image at model load)
-  float *park;         // [n_ld/128][h_ld/128][64 KB] scratch: l2 + l3 of a tile while l0, l1 run
+  float *park;         // [n_ld/128][h_ld/128][64 KB] scratch: l2 + l3 of a tile while l0, l1 run (128-node tiles only, else null)
   int j_pad, jc;       // D/4 rounded up to the chunk depth jc = l0_chunk_rows(D)
   int n_ld, h_ld;      // image row lengths: frame capacity and H, both rounded up to 128
 };
 void launch_l0(const L0Params &p, hipStream_t s);
 int l0_chunk_rows(int D);
+int l0_chain_node_tile();  // 64 (default: no park scratch needed) or 128 (L0Params::park must be allocated)
 void launch_l0_weight_image(const float *w, float *wt, int H, int D, int j_pad, int h_ld, hipStream_t s);
 
 // Frame tile (32/64/128/160/256/320) the int8 GEMM should use for `n` frames of a layer

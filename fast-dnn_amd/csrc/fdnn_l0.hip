@@ -216,6 +216,9 @@ typedef float v32f __attribute__((ext_vector_type(32)));
 #ifndef FDNN_L0_SCHED_MASK
 #define FDNN_L0_SCHED_MASK 0x3f4  // what may cross the products | adds fence of the chain kernel: memory and scalar ops
 #endif
+#ifndef FDNN_L0_TN64_WAVES
+#define FDNN_L0_TN64_WAVES 3  // waves per SIMD the 64-node chain kernel is compiled for (134 VGPRs as written)
+#endif
 #ifndef FDNN_L0_DEBUG
 #define FDNN_L0_DEBUG 0  // kernel-ablation timing builds only (tools/build_variant.sh): 1 no MFMA, 2 no loads in the k-loop;
                          // chain kernel: 4 operands from registers (no LDS reads), 8 no LDS-DMA in the loop
@@ -248,13 +251,23 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float *base
 //
 // 256 threads = 16 (tx: nodes) x 16 (ty: frames); thread owns frames {4ty..4ty+3, 64+4ty..} and
 // nodes {4tx..4tx+3, 64+4tx..}; frame pairs ride v_pk_mul_f32 / v_pk_add_f32.
-template <int JC, bool TAP>
-__global__ __launch_bounds__(256, 2) void l0_chain_kernel(L0Params p) {
+// TN = 128: 8 x 8 outputs per thread, t = l2 + l3 parked in global scratch (two 64-register sets
+// live).  TN = 64: 8 frames x 4 nodes per thread -- 32 accumulators per chain, so l2 + l3 STAYS IN
+// REGISTERS (three 32-register sets live), no park traffic at all (the 128-wide tile moves 82 MB
+// out and back per launch, 8x the kernel's algorithmic bytes), and the smaller register
+// footprint admits three workgroups per CU; the price is 1.5 LDS bytes per MAC instead of 1.
+template <int JC, int TN, bool TAP>
+__global__ __launch_bounds__(256, TN == 128 ? 2 : FDNN_L0_TN64_WAVES) void l0_chain_kernel(L0Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins are device-only
-  constexpr int TF = 128, TN = 128, NST = 3;
+  constexpr int TF = 128, NST = 3;
+  constexpr int NA = TN / 16;              // nodes per thread: 8 or 4
   constexpr int STAGE_F = JC * (TF + TN);  // floats per stage
-  constexpr int NLD = JC / 4;              // 1-KiB loads per wave and stage: JC/2 frame row pairs + JC/2 node row pairs
-  static_assert(JC % 4 == 0, "a stage is split evenly over four waves");
+  constexpr int NX = JC / 2;               // 1-KiB wave loads per stage: frame rows, two per load
+  constexpr int NW = TN == 128 ? JC / 2 : JC / 4;  // node rows: two (512 B) or four (256 B) per load
+  constexpr int NI = NX + NW;
+  constexpr int NLD = NI / 4;              // FEWEST loads any of the four waves issues per stage (vmcnt bound)
+  static_assert(JC % 4 == 0, "a stage is split over four waves");
+  static_assert(TN == 128 || TN == 64, "node tile");
   typedef float v2f __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) float smem[];  // NST stages, then the sigmoid table
   uint8_t *lut = reinterpret_cast<uint8_t *>(smem + NST * STAGE_F);
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void l0_chain_kernel(L0Params p) {
 
   const int NQ = p.j_pad / JC, NS = 4 * NQ;  // stage s = (pass s / NQ, chunk s % NQ): image row s * JC
   const int voff_x = ((lane >> 5) * p.n_ld + (lane & 31) * 4) * 4;
-  const int voff_w = ((lane >> 5) * p.h_ld + (lane & 31) * 4) * 4;
+  const int voff_w = TN == 128 ? ((lane >> 5) * p.h_ld + (lane & 31) * 4) * 4 : ((lane >> 4) * p.h_ld + (lane & 15) * 4) * 4;
   const size_t x_ld = static_cast<size_t>(p.n_ld), w_ld = static_cast<size_t>(p.h_ld);
   auto issue = [&](int s, int buf) {
     const size_t row0 = static_cast<size_t>(s) * JC;
@@ -276,25 +289,25 @@ __global__ __launch_bounds__(256, 2) void l0_chain_kernel(L0Params p) {
     const auto rsrc_w = uniform_rsrc(p.wt + row0 * w_ld + n0, JC * p.h_ld * 4);
     float *base = smem + buf * STAGE_F;
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
+    for (int i = 0; i < (NI + 3) / 4; ++i) {
       const int u = i * 4 + wave;
-      if (u < JC / 2)
+      if (u < NX)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, FDNN_LDS_PTR(base + u * 256), 16, voff_x, u * 2 * p.n_ld * 4, 0, 0);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, FDNN_LDS_PTR(base + JC * TF + (u - JC / 2) * 256), 16, voff_w,
-                                                 (u - JC / 2) * 2 * p.h_ld * 4, 0, 0);
+      else if (u < NI)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, FDNN_LDS_PTR(base + JC * TF + (u - NX) * 256), 16, voff_w,
+                                                 (u - NX) * (TN == 128 ? 2 : 4) * p.h_ld * 4, 0, 0);
     }
   };
 
   // Pass order 2, 3, 0, 1 (the images store their planes in that order): l2 waits in registers
-  // while l3 runs, t = l2 + l3 is parked in global scratch (64 KB per tile, read back from L2
-  // two passes later), l0 waits while l1 runs -> never more than two 64-register sets live.
-  v2f acc[8][4], held[8][4];
+  // while l3 runs, t = l2 + l3 is parked (TN = 128: in global scratch, 64 KB per tile, read back
+  // from L2 two passes later; TN = 64: in 32 registers), l0 waits while l1 runs.
+  v2f acc[NA][4], held[NA][4], tsum[TN == 64 ? NA : 1][4];
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < NA; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = held[a][b] = v2f{0.0f, 0.0f};
-  v2f *park = reinterpret_cast<v2f *>(p.park) + (static_cast<size_t>(by) * (p.h_ld / TN) + bx) * (32 * 256) + tid;
+  v2f *park = reinterpret_cast<v2f *>(p.park) + (static_cast<size_t>(by) * (p.h_ld / 128) + bx) * (32 * 256) + tid;  // TN = 128 only
 
   issue(0, 0);
   if (NS > 1) issue(1, 1);
@@ -325,12 +338,13 @@ __global__ __launch_bounds__(256, 2) void l0_chain_kernel(L0Params p) {
       const v4f xa = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(xb) + (j * TF + ty * 4) * 4);
       const v4f xc = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(xb) + (j * TF + 64 + ty * 4) * 4);
       const v4f wa = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(wb) + (j * TN + tx * 4) * 4);
-      const v4f wc = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(wb) + (j * TN + 64 + tx * 4) * 4);
+      v4f wc = wa;
+      if (TN == 128) wc = *reinterpret_cast<const v4f *>(reinterpret_cast<const char *>(wb) + (j * TN + 64 + tx * 4) * 4);
 #endif
       const v2f xp[4] = {{xa.x, xa.y}, {xa.z, xa.w}, {xc.x, xc.y}, {xc.z, xc.w}};
       const float wv[8] = {wa.x, wa.y, wa.z, wa.w, wc.x, wc.y, wc.z, wc.w};
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < NA / 2; ++g) {
         // InputActivations, canonical flavour: multiply and add rounded separately (dnn.cc:233-238);
         // eight products first, so that no add waits on the multiply right before it
         v2f pr[2][4];
@@ -351,19 +365,21 @@ __global__ __launch_bounds__(256, 2) void l0_chain_kernel(L0Params p) {
       q = 0;
       if (pass == 0 || pass == 2) {  // l2 / l0 done: hold it, start l3 / l1 from zero
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
             held[a][b] = acc[a][b];
             acc[a][b] = v2f{0.0f, 0.0f};
           }
-      } else if (pass == 1) {  // t = l2 + l3 -> scratch
+      } else if (pass == 1) {  // t = l2 + l3 -> scratch (TN = 128) / registers (TN = 64)
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < NA; ++a)
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
             const v2f t = held[a][b] + acc[a][b];
-            if (FDNN_WT & 4)  // read back from L2 either way; written through, it is not dirty when the kernel ends
+            if (TN == 64)
+              tsum[TN == 64 ? a : 0][b] = t;
+            else if (FDNN_WT & 4)  // read back from L2 either way; written through, it is not dirty when the kernel ends
               store_wt(park + (a * 4 + b) * 256, v2f_t{t.x, t.y});
             else
               park[(a * 4 + b) * 256] = t;
@@ -374,23 +390,23 @@ __global__ __launch_bounds__(256, 2) void l0_chain_kernel(L0Params p) {
     }
   }
   // held = l0, acc = l1.  AddBias + QuantizedSigmoid; node quads go out as one dword per frame.
-  float bias[8];
+  float bias[NA];
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
+  for (int a = 0; a < NA; ++a) {
     const int node = n0 + (a >> 2) * 64 + tx * 4 + (a & 3);
     bias[a] = node < p.H ? p.bias[node] : 0.0f;
   }
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    v2f lin2[8];
+    v2f lin2[NA];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) lin2[a] = (held[a][b] + acc[a][b]) + park[(a * 4 + b) * 256];
+    for (int a = 0; a < NA; ++a) lin2[a] = (held[a][b] + acc[a][b]) + (TN == 64 ? tsum[TN == 64 ? a : 0][b] : park[(a * 4 + b) * 256]);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int f = f0 + (b >> 1) * 64 + ty * 4 + (b & 1) * 2 + h;
       if (f >= p.n_rows) continue;
 #pragma unroll
-      for (int grp = 0; grp < 2; ++grp) {
+      for (int grp = 0; grp < NA / 4; ++grp) {
         uint32_t packed = 0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -452,17 +468,25 @@ __global__ __launch_bounds__(256) void l0_image_kernel(const float *src, const f
   }
 }
 
-template <int JC>
-void launch_chain(const L0Params &p, hipStream_t s) {
+template <int JC, int TN>
+void launch_chain_tn(const L0Params &p, hipStream_t s) {
   const int cols = (p.n_rows + 127) / 128 * 128;
   hipLaunchKernelGGL(l0_image_kernel, dim3(cols / 64, (p.j_pad * 4 + 63) / 64), dim3(256), 0, s, p.x, p.shift, p.scale, p.xt, p.n,
                      p.D, p.j_pad, p.n_ld);
-  dim3 grid(l0_grid(p.h_ld / 128, cols / 128));
-  constexpr size_t lds = sizeof(float) * (3 * JC * 256 + (kLutExt + 15) / 16 * 4);
+  dim3 grid(l0_grid(p.h_ld / TN, cols / 128));
+  constexpr size_t lds = sizeof(float) * (3 * JC * (128 + TN) + (kLutExt + 15) / 16 * 4);
   if (p.tap_lin)
-    hipLaunchKernelGGL((l0_chain_kernel<JC, true>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((l0_chain_kernel<JC, TN, true>), grid, dim3(256), lds, s, p);
   else
-    hipLaunchKernelGGL((l0_chain_kernel<JC, false>), grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL((l0_chain_kernel<JC, TN, false>), grid, dim3(256), lds, s, p);
+}
+
+template <int JC>
+void launch_chain(const L0Params &p, hipStream_t s) {
+  if (l0_chain_node_tile() == 64)
+    launch_chain_tn<JC, 64>(p, s);
+  else
+    launch_chain_tn<JC, 128>(p, s);
 }
 
 template <int BK, int WFR>
@@ -657,6 +681,20 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   // 64 x 64 tile, 16-float chunks, 4 x 4 outputs per thread.  Measured alternatives: 32-float
   // chunks 0.448 ms, 8 x 4 outputs per thread 0.468 / 0.477 ms (occupancy 2) against 0.388.
   launch_valu<4, 16>(p, s);
+}
+
+// Node tile of the chain kernel: 64 (8 frames x 4 nodes per thread, every partial sum in registers,
+// three workgroups per CU) or 128 (8 x 8, l2 + l3 parked in a global scratch buffer).  Both run
+// at the same speed -- the kernel is bound by vector-instruction issue, 329.8 vs 331.7 us at
+// 10 000 frames (rocprofv3) -- but the 64-wide tile moves 164 MB less through HBM per launch and
+// needs no scratch, which is what the soft-max scale running underneath it in the server loop
+// competes for.  FDNN_L0_TN=128 selects the round-1 shape.
+int l0_chain_node_tile() {
+  static const int tn = [] {
+    const char *e = std::getenv("FDNN_L0_TN");
+    return (e && std::atoi(e) == 128) ? 128 : 64;
+  }();
+  return tn;
 }
 
 int l0_chunk_rows(int D) {

@@ -148,7 +148,8 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
   alloc(reinterpret_cast<void **>(&c->d_x), sizeof(float) * np * h.in_dim);
   c->xt_ld = round_up(c->cap, 128);
   alloc(reinterpret_cast<void **>(&c->d_xt), sizeof(float) * 4 * size_t(m->l0_j_pad) * c->xt_ld);
-  alloc(reinterpret_cast<void **>(&c->d_l0park), sizeof(float) * size_t(c->xt_ld) * m->l0_h_ld);
+  if (fdnn::l0_chain_node_tile() == 128)  // the 64-node tile keeps its partial sums in registers
+    alloc(reinterpret_cast<void **>(&c->d_l0park), sizeof(float) * size_t(c->xt_ld) * m->l0_h_ld);
   alloc(reinterpret_cast<void **>(&c->d_act[0]), npt * c->act_ld);
   alloc(reinterpret_cast<void **>(&c->d_act[1]), npt * c->act_ld);
   alloc(reinterpret_cast<void **>(&c->d_out), sizeof(float) * np * h.out_dim);
