@@ -126,3 +126,28 @@ def test_calculate_through_the_model_batcher(mid_model_path):
         assert np.array_equal(g, want[i % 12]), i
     assert dnn.calculate(np.zeros((0, 432), np.float32)).shape == (0, 0)
     dnn.delete()
+
+
+def test_server_argument_errors(tiny_model_path):
+    dnn = api.QuantizedDnn.loadFromFile(tiny_model_path)
+    with pytest.raises(api.FdnnError) as e:
+        api.ScoringServer(dnn, 0, 2)
+    assert e.value.code == api.FDNN_E_ARG
+    with pytest.raises(api.FdnnError):
+        api.ScoringServer(dnn, 100, 17)
+    srv = api.ScoringServer(dnn, 64, 2)
+    with pytest.raises(api.FdnnError) as e:
+        srv.wait(12345)  # never issued
+    assert e.value.code == api.FDNN_E_ARG
+    with pytest.raises(ValueError):
+        srv.submit(np.zeros((3, 429), np.float32))
+    x = F.synth_features(10, 432, seed=1)
+    with pytest.raises(ValueError):
+        srv.submit(x, masks=np.ones((10, 99), np.int8))
+    t, out = srv.submit(x)
+    srv.wait(t)
+    srv.wait(t)  # waiting twice is harmless
+    assert np.array_equal(out, dnn.calculate(x))
+    srv.drain()
+    srv.close()
+    dnn.delete()

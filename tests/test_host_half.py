@@ -111,6 +111,9 @@ def test_no_cpu_fallback_without_a_gpu(tiny_model_path):
     with pytest.raises(api.FdnnError) as e:
         api.QuantizedDnn.loadFromFile(tiny_model_path)
     assert e.value.code == api.FDNN_E_DEVICE and "no CPU path" in str(e.value)
+    with pytest.raises(api.FdnnError) as e:  # the group entry points sit on the same loader
+        api.DeviceGroup(tiny_model_path, [0, 0])
+    assert e.value.code == api.FDNN_E_DEVICE
 
 
 def test_product_never_touches_the_oracle():

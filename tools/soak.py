@@ -1,5 +1,7 @@
-"""Soak: many batch sizes through every kernel-selection branch, checked for determinism (same
-input -> same bits) and soft-max rows summing to one.  tools/soak.py [iterations]"""
+"""Soak: many batch sizes through every kernel-selection branch -- dense, masked (lazy contract) and
+through the scoring loop -- checked for determinism (same input -> same bits), soft-max rows
+summing to one, masked-out nodes reading one value per row, and all-ones masks == dense.
+tools/soak.py [iterations]"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
@@ -25,4 +27,32 @@ for it in range(iters):
     assert torch.equal(a, b), (it, n, fma)
     rs = a.sum(1)
     assert float((rs - 1).abs().max()) < 1e-3, (it, n, fma, float(rs.min()), float(rs.max()))
+    # masked leg: the same frames through the lazy contract (device pointers), twice, + all-ones == dense
+    if it % 3 == 0:
+        m = (torch.rand((n, 8000), device="cuda") < 0.4).to(torch.int8)
+        ctx = dnn.getNewLazyContext(n)
+        la = torch.empty_like(a); lb = torch.empty_like(a)
+        ctx.calculateUntilOutputDevice(x.data_ptr(), s)
+        ctx.calculateForOutputNodesBatchDevice(m.data_ptr(), la.data_ptr(), 0, n, s)
+        ctx.calculateForOutputNodesBatchDevice(m.data_ptr(), lb.data_ptr(), 0, n, s)
+        torch.cuda.synchronize()
+        assert torch.equal(la, lb), ("masked", it, n, fma)
+        assert float((la.sum(1) - 1).abs().max()) < 1e-3, ("masked sum", it, n)
+        off = m == 0
+        lo = torch.where(off, la, torch.full_like(la, float("inf"))).min(1).values
+        hi = torch.where(off, la, torch.full_like(la, float("-inf"))).max(1).values
+        assert bool((lo == hi).all()), ("masked-out nodes differ within a row", it, n)
+        m.fill_(1)
+        ctx.calculateForOutputNodesBatchDevice(m.data_ptr(), la.data_ptr(), 0, n, s)
+        torch.cuda.synchronize()
+        assert torch.equal(la, a), ("all-ones mask != dense", it, n, fma)
+        ctx.delete()
+    # scoring-loop leg: two submissions in flight == the single-stream result
+    if it % 5 == 0:
+        srv = api.ScoringServer(dnn, n, 2)
+        sa = torch.empty_like(a); sb = torch.empty_like(a)
+        t1 = srv.submit_device(x.data_ptr(), n, sa.data_ptr()); t2 = srv.submit_device(x.data_ptr(), n, sb.data_ptr())
+        srv.wait(t2); srv.wait(t1)
+        assert torch.equal(sa, a) and torch.equal(sb, a), ("server", it, n, fma)
+        srv.close()
 print(f"soak ok: {iters} iterations in {time.time() - t0:.1f} s")
