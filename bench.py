@@ -22,6 +22,7 @@ Rank 0 prints ONE JSON line (contract in the task statement) with
   roofline_int8_gemm   the hidden-layer int8 GEMM by name (the MFMA kernel the net is made of)
   end_to_end           value against the int8-MFMA ceiling of the whole net (60 M frames/s)
   lazy_40pct           BASELINE configs[3]: LazyContext contract, 40 % mask with 3 % churn, same batch
+  serving              16 caller threads x 100-frame utterances host-to-host: streams at real time per GPU
   cpu_baseline         the reference algorithm (oracle SSE4.1 port) on this host's cores, N=1 only
 Setup (model load, 0.5 s of untimed passes that bring a cold device to its sustained clocks,
 reported as `setup.clock_ramp_steps`) comes before the W warm-up steps.
@@ -149,6 +150,7 @@ def main() -> None:
     ap.add_argument("--in-flight", type=int, default=2, help="steps in flight in the scoring loop (1 = no overlap between steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lazy", action="store_true", help="skip the configs[3] leg")
+    ap.add_argument("--no-serving", action="store_true", help="skip the 100-frame-utterance serving leg")
     ap.add_argument("--clock-ramp-s", type=float, default=0.5, help="seconds of untimed load before the W warm-up steps (setup)")
     ap.add_argument("--single-stream-only", action="store_true",
                     help="profiling runs (tools/profile_round.sh): only the back-to-back single-stream steps, so that rocprofv3's "
@@ -321,6 +323,53 @@ def main() -> None:
         }
         del md, masks
 
+    # ---- the serving shape: 16 caller threads, 100-frame utterances (1 s of speech each), host buffers
+    serving = None
+    if world == 1 and not args.no_serving:
+        import threading
+
+        T, per, uf = 16, 60, 100
+        utt = F.synth_features(uf, 432, seed=5)
+        bufs = [np.zeros((uf, O), dtype=np.float32) for _ in range(T)]  # resident, reused (a JVM float[] would be)
+        ssrv = api.ScoringServer(dnn, 6400, 3, 100)
+
+        def via_server(t):
+            for _ in range(per):
+                tk, _o = ssrv.submit(utt, out=bufs[t])
+                ssrv.wait(tk)
+
+        def per_call(t):
+            for _ in range(per):
+                dnn.calculate(utt)
+
+        def run(fn):
+            th = [threading.Thread(target=fn, args=(t,)) for t in range(T)]
+            t0_ = time.perf_counter()
+            for h in th:
+                h.start()
+            for h in th:
+                h.join()
+            return T * per / (time.perf_counter() - t0_)
+
+        run(via_server)
+        s_rate = run(via_server)
+        st = ssrv.stats()
+        ssrv.close()
+        run(per_call)
+        p_rate = run(per_call)
+        assert abs(float(bufs[0].sum(1).mean()) - 1.0) < 1e-3
+        serving = {
+            "workload": f"{T} caller threads x {per} utterances of {uf} frames (1 s of speech), host frames in, host soft-max rows out "
+                        f"({uf * O * 4 / 1e6:.1f} MB per utterance)",
+            "utterances_per_s_through_the_scoring_loop": round(s_rate, 1),
+            "utterances_per_s_per_call_fdnn_calculate": round(p_rate, 1),
+            "streams_at_real_time": round(max(s_rate, p_rate), 1),
+            "device_to_host_GB_per_s": round(max(s_rate, p_rate) * uf * O * 4 / 1e9, 1),
+            "batches": st["batches"], "requests": st["requests"],
+            "note": "Python caller threads (ctypes releases the GIL inside the library); tools/serve_bench.cpp is the native "
+                    "harness (profiles/r02_serve_bench_raw.log); bound by PCIe + host memcpy of the 32 KB per frame, not by the GPU",
+        }
+
     srv.close()
     if rank == 0:
         steps = args.steps
@@ -424,6 +473,7 @@ def main() -> None:
                 "layer0_numerics": "unfused (canonical)" if args.l0_fma else "fused (reference built -march=native), fp32 MFMA",
                 "frames_per_s_single_stream": round(alt, 1)},
             "lazy_40pct": lazy,
+            "serving": serving,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(model_path)

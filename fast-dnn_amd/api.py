@@ -302,8 +302,9 @@ class ScoringServer:
                                                C.c_void_p(d_out), C.byref(t)))
         return int(t.value)
 
-    def submit(self, x, masks=None):
-        """Host frames -> (ticket, out array).  ``out`` is valid after ``wait(ticket)``."""
+    def submit(self, x, masks=None, out=None):
+        """Host frames -> (ticket, out array).  ``out`` is valid after ``wait(ticket)``; pass a
+        C-contiguous float32 [n][output_dim] array to have the result written there (reused buffers)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         if x.ndim != 2 or x.shape[1] != self.dnn.inputDimension():
             raise ValueError(f"Input vector size {x.shape[-1]} must be equal with network input size {self.dnn.inputDimension()}")
@@ -313,7 +314,10 @@ class ScoringServer:
             m = np.ascontiguousarray(masks, dtype=np.int8)
             if m.shape != (x.shape[0], O):
                 raise ValueError(f"masks must be {x.shape[0]} x {O}, got {m.shape}")
-        out = np.empty((x.shape[0], O), dtype=np.float32)
+        if out is None:
+            out = np.empty((x.shape[0], O), dtype=np.float32)
+        elif out.dtype != np.float32 or out.shape != (x.shape[0], O) or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous float32 array of shape {(x.shape[0], O)}")
         t = C.c_uint64()
         _check(lib().fdnn_server_submit(self.handle, x.ctypes.data_as(_c_f32p), x.shape[0],
                                         m.ctypes.data_as(_c_i8p) if m is not None else None, out.ctypes.data_as(_c_f32p), C.byref(t)))

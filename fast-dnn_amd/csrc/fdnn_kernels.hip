@@ -16,6 +16,11 @@ namespace {
 // sum of the output kernel's per-64-node partials in a fixed order.
 // dst == out scales in place; the per-frame lazy call passes a host-mapped dst instead, so the
 // probabilities land in the caller's pinned buffer without a copy command.
+#ifndef FDNN_NORM_BG_NT
+#define FDNN_NORM_BG_NT 1  // non-temporal loads / stores in the background scale kernel: its 640 MB stream through the
+                           // L2s that layer 0 (running beside it) keeps its operand images in; +2 % on the overlapped step
+#endif
+template <bool NT>
 __device__ __forceinline__ void normalize_row(const float *out, float *dst, const float *partial, int f, int partial_ld, int rows,
                                               int n_partial, float *red) {
   const int tid = threadIdx.x;
@@ -50,12 +55,20 @@ __device__ __forceinline__ void normalize_row(const float *out, float *dst, cons
     float4 *d4 = reinterpret_cast<float4 *>(drow + head);
     const int groups = (rows - head) >> 2, tail0 = head + 4 * groups;
     for (int i = tid; i < groups; i += 256) {
-      float4 v = r4[i];
+      float4 v;
+      if (NT) {
+        const v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(r4 + i));
+        v = make_float4(t.x, t.y, t.z, t.w);
+      } else {
+        v = r4[i];
+      }
       v.x = v.x * inv;
       v.y = v.y * inv;
       v.z = v.z * inv;
       v.w = v.w * inv;
-      if ((FDNN_WT & 32) && wt_rows)
+      if (NT)
+        __builtin_nontemporal_store(v4f_t{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f_t *>(d4 + i));
+      else if ((FDNN_WT & 32) && wt_rows)
         store_wt(d4 + i, v4f_t{v.x, v.y, v.z, v.w});
       else
         d4[i] = v;
@@ -70,7 +83,7 @@ __device__ __forceinline__ void normalize_row(const float *out, float *dst, cons
 __global__ __launch_bounds__(256) void normalize_kernel(const float *out, float *dst, const float *partial, int n, int partial_ld,
                                                         int rows, int n_partial) {
   __shared__ float red[4];
-  normalize_row(out, dst, partial, blockIdx.x, partial_ld, rows, n_partial, red);
+  normalize_row<false>(out, dst, partial, blockIdx.x, partial_ld, rows, n_partial, red);
 }
 
 // The same pass as a BACKGROUND kernel for the server loop: a fixed, small grid of workgroups that
@@ -83,7 +96,7 @@ __global__ __launch_bounds__(256) void normalize_bg_kernel(const float *out, flo
                                                            int partial_ld, int rows, int n_partial) {
   __shared__ float red[4];
   for (int f = blockIdx.x; f < n; f += gridDim.x) {
-    normalize_row(out, dst, partial, f, partial_ld, rows, n_partial, red);
+    normalize_row<(FDNN_NORM_BG_NT != 0)>(out, dst, partial, f, partial_ld, rows, n_partial, red);
     __syncthreads();  // red[] is reused by the next row
   }
 }
@@ -185,7 +198,7 @@ void launch_normalize(float *out, float *dst, const float *partial, int n, int p
   if (background) {
     static const int wgs = [] {
       const char *e = std::getenv("FDNN_NORM_BG_WGS");
-      return e ? std::max(1, std::atoi(e)) : 512;
+      return e ? std::max(1, std::atoi(e)) : 256;  // sweep, 2 steps in flight: 192-256 best (+7-8 % over one stream), 512 +4 %, 1024 +2 %
     }();
     hipLaunchKernelGGL(normalize_bg_kernel, dim3(std::min(n, wgs)), dim3(256), 0, s, out, dst, partial, n, partial_ld, rows, n_partial);
     return;

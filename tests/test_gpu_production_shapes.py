@@ -216,3 +216,18 @@ def test_sigmoid_table_ends(tmp_models, exact_path):
     assert (ctx.hiddenActivations() == u[-1]).all()
     ctx.delete()
     dnn.delete()
+
+
+def test_layer0_128_node_tile_still_bit_exact():
+    """The chain kernel ships on 64-node tiles (partial sums in registers); the round-1 shape --
+    128-node tiles with l2 + l3 parked in global scratch -- stays selectable (FDNN_L0_TN=128, read
+    once per process): run the layer-0 parity tests under it in a child process."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, FDNN_L0_TN="128")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "input_widths or tiny_golden or blob_export or ragged_batch"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -151,3 +151,48 @@ def test_server_argument_errors(tiny_model_path):
     srv.drain()
     srv.close()
     dnn.delete()
+
+
+def test_host_and_device_submissions_share_one_server(mid_model_path):
+    """Both kinds of submission on the same slots at the same time: host utterances from worker
+    threads (coalesced, staged through the slot's pinned buffers) while the main thread keeps
+    device-resident batches in flight; every result equals the per-call API's."""
+    import torch
+
+    dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+    O = dnn.outputDimension()
+    utts = [F.synth_features(50 + 30 * i, 432, seed=800 + i) for i in range(6)]
+    want = [dnn.calculate(u) for u in utts]
+    n = 3000  # above the small-batch threshold: compute stream + tail stream
+    xd = torch.from_numpy(F.synth_features(n, 432, seed=9)).cuda()
+    ref = torch.empty((n, O), dtype=torch.float32, device="cuda")
+    dnn.calculate_device(xd.data_ptr(), n, ref.data_ptr(), 0)
+    torch.cuda.synchronize()
+    srv = api.ScoringServer(dnn, n, 2, 50)
+    errors, got = [], {}
+
+    def host_worker(w):
+        try:
+            for j in range(20):
+                i = (j + w) % len(utts)
+                t, out = srv.submit(utts[i])
+                srv.wait(t)
+                got[(w, j)] = (i, out)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=host_worker, args=(w,)) for w in range(4)]
+    for t in th:
+        t.start()
+    outs = [torch.zeros((n, O), dtype=torch.float32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for k in range(30):
+        srv.wait(srv.submit_device(xd.data_ptr(), n, outs[k % 2].data_ptr()))
+        assert torch.equal(outs[k % 2], ref), k
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for (w, j), (i, out) in got.items():
+        assert np.array_equal(out, want[i]), (w, j)
+    srv.close()
+    dnn.delete()
