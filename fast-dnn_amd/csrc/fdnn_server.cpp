@@ -48,7 +48,15 @@ struct Piece {  // one caller's rows inside a coalesced batch
   uint64_t ticket;
   float *out;      // caller's destination of these rows
   int row0, rows;  // rows [row0, row0 + rows) of the batch
-  bool last;       // completes the ticket
+  bool last;       // the ticket's final piece
+  int state = 0;   // 0 batch in flight, 1 rows ready in the slot's pinned buffer, 2 being copied out, 3 done
+};
+
+struct TicketState {
+  int status = 0;      // 0 running, != 0 failed with that fdnn_status
+  int created = 0;     // pieces packed so far
+  int done = 0;        // pieces copied out
+  bool closed = false; // the final piece has been packed
 };
 
 struct Request {
@@ -67,10 +75,11 @@ struct Slot {
   uint64_t ticket = 0;            // device submissions: the ticket this slot last carried
   bool used = false;              // `done` has been recorded at least once
   // host submissions (allocated on first use)
-  float *h_x = nullptr, *h_out = nullptr, *d_out = nullptr;
+  float *h_x = nullptr, *d_out = nullptr;
   int8_t *h_mask = nullptr;
   std::vector<Piece> pieces;
   int frames = 0;
+  int pieces_left = 0;            // pieces of the current host batch not copied out yet
   bool in_flight = false;         // host batch enqueued, not yet scattered
 };
 
@@ -90,7 +99,7 @@ struct fdnn_server {
   std::condition_variable qcv, done_cv, slot_cv;
   std::deque<Request> queue;
   std::deque<int> flying;         // slots with a host batch enqueued, in launch order
-  std::unordered_map<uint64_t, int> pending;  // host ticket -> 0 running, >0 failed with that status
+  std::unordered_map<uint64_t, TicketState> pending;  // host tickets not yet complete (a failed one stays until waited for)
   std::thread packer, finisher;
   bool stop = false;
   bool host_ready = false;
@@ -106,7 +115,6 @@ int alloc_host_side(fdnn_server *s) {
   for (Slot &sl : s->slots) {
     const size_t n = size_t(s->max_frames);
     hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_x), sizeof(float) * n * h.in_dim, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_out), sizeof(float) * n * h.out_dim, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_mask), n * h.out_dim, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&sl.d_out), sizeof(float) * n * h.out_dim);
     if (e != hipSuccess)
@@ -144,18 +152,46 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
   return FDNN_OK;
 }
 
-void complete_ticket(fdnn_server *s, uint64_t ticket, int status) {
-  {
-    std::lock_guard<std::mutex> lk(s->qmu);
-    auto it = s->pending.find(ticket);
-    if (it != s->pending.end()) {
-      if (status)
-        it->second = status;  // keep the failure for the waiter
-      else
-        s->pending.erase(it);
+// Hands rows back to their callers.  The rows of a finished batch sit in the slot's device buffer; whoever gets
+// there first copies a piece out -- the caller blocked in fdnn_server_wait (so that many callers copy in
+// parallel: 3.2 MB per 100-frame utterance, one thread's copies would be the slowest stage of the loop) or the
+// finisher thread (so that a ticket nobody waits for cannot hold a slot).  Call with qmu held; the lock is
+// dropped around each memcpy.  `only_ticket` = 0 takes any ready piece of the slot.
+void copy_ready_pieces(fdnn_server *s, std::unique_lock<std::mutex> &lk, Slot &sl, uint64_t only_ticket) {
+  const size_t O = size_t(s->m->hm.hdr.out_dim);
+  for (size_t i = 0; i < sl.pieces.size(); ++i) {
+    Piece &p = sl.pieces[i];
+    if (p.state != 1 || (only_ticket && p.ticket != only_ticket)) continue;
+    p.state = 2;
+    const Piece job = p;  // the vector is stable while in_flight, but copy what the unlocked part needs anyway
+    lk.unlock();
+    // straight from the slot's device buffer into the caller's memory, on the copying thread's own stream: no pinned
+    // bounce buffer and no second pass over the 32 KB per frame
+    hipError_t ce;
+    {
+      DeviceGuard dg(s->m->device);
+      ce = hipMemcpyAsync(job.out, sl.d_out + size_t(job.row0) * O, sizeof(float) * size_t(job.rows) * O, hipMemcpyDeviceToHost,
+                          hipStreamPerThread);
+      if (ce == hipSuccess) ce = hipStreamSynchronize(hipStreamPerThread);
     }
+    lk.lock();
+    sl.pieces[i].state = 3;
+    auto it = s->pending.find(job.ticket);
+    bool finished = false;
+    if (it != s->pending.end()) {
+      it->second.done++;
+      if (ce != hipSuccess) it->second.status = FDNN_E_DEVICE;
+      if (it->second.closed && it->second.done == it->second.created && it->second.status == 0) {
+        s->pending.erase(it);
+        finished = true;
+      }
+    }
+    if (--sl.pieces_left == 0) {
+      sl.in_flight = false;
+      s->slot_cv.notify_all();
+    }
+    if (finished || ce != hipSuccess) s->done_cv.notify_all();
   }
-  s->done_cv.notify_all();
 }
 
 // Packs queued requests into batches and enqueues them.
@@ -206,11 +242,19 @@ void packer_loop(fdnn_server *s) {
       any_mask |= r.masks != nullptr;
       r.taken += take;
       const bool last = r.taken == r.n;
-      sl.pieces.push_back(Piece{r.ticket, r.out + size_t(part.taken) * O, rows, take, last});
+      sl.pieces.push_back(Piece{r.ticket, r.out + size_t(part.taken) * O, rows, take, last, 0});
+      {
+        auto it = s->pending.find(r.ticket);
+        if (it != s->pending.end()) {
+          it->second.created++;
+          if (last) it->second.closed = true;
+        }
+      }
       rows += take;
       if (last) s->queue.pop_front();
     }
     sl.frames = rows;
+    sl.pieces_left = int(sl.pieces.size());
     sl.in_flight = true;
     s->host_next_slot = uint64_t(si) + 1;
     lk.unlock();
@@ -242,8 +286,7 @@ void packer_loop(fdnn_server *s) {
           e = hipEventRecord(sl.gemm_done, last);  // (gemm_done is free again: the scale pass already waits on its earlier record)
           if (e == hipSuccess) e = hipStreamWaitEvent(sl.stream, sl.gemm_done, 0);
         }
-        if (e == hipSuccess) e = hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(float) * size_t(rows) * O, hipMemcpyDeviceToHost, sl.stream);
-        if (e == hipSuccess) e = hipEventRecord(sl.done, sl.stream);
+        if (e == hipSuccess) e = hipEventRecord(sl.done, sl.stream);  // the rows leave later, piece by piece (copy_ready_pieces)
       }
     }
     if (e != hipSuccess) rc = fail(FDNN_E_DEVICE, std::string("server batch: ") + hipGetErrorString(e));
@@ -254,9 +297,10 @@ void packer_loop(fdnn_server *s) {
       std::lock_guard<std::mutex> lk2(s->qmu);
       if (rc) {  // nothing usable was enqueued: fail the tickets, free the slot
         sl.in_flight = false;
+        sl.pieces_left = 0;
         for (const Piece &p : sl.pieces) {
           auto it = s->pending.find(p.ticket);
-          if (it != s->pending.end()) it->second = rc;
+          if (it != s->pending.end()) it->second.status = rc;
         }
       } else {
         s->flying.push_back(si);
@@ -271,10 +315,9 @@ void packer_loop(fdnn_server *s) {
   }
 }
 
-// Waits for enqueued host batches in launch order and hands the rows back.
+// Waits for enqueued host batches in launch order, marks their rows ready and helps copying them out.
 void finisher_loop(fdnn_server *s) {
   DeviceGuard g(s->m->device);
-  const size_t O = size_t(s->m->hm.hdr.out_dim);
   for (;;) {
     int si;
     {
@@ -289,30 +332,22 @@ void finisher_loop(fdnn_server *s) {
     }
     Slot &sl = s->slots[size_t(si)];
     const hipError_t e = hipEventSynchronize(sl.done);
-    const int status = e == hipSuccess ? FDNN_OK : FDNN_E_DEVICE;
-    if (!status) {
-      // hand the rows back: 32 KB per frame, so a full batch is hundreds of MB -- one thread's
-      // memcpy (~10 GB/s) would be the slowest stage of the loop; a few helpers share the pieces
-      const size_t total = sizeof(float) * size_t(sl.frames) * O;
-      const int helpers = total > (size_t(8) << 20) ? int(std::min<size_t>(6, sl.pieces.size())) : 1;
-      auto copy_share = [&](int t) {
-        for (size_t i = size_t(t); i < sl.pieces.size(); i += size_t(helpers)) {
-          const Piece &p = sl.pieces[i];
-          std::memcpy(p.out, sl.h_out + size_t(p.row0) * O, sizeof(float) * size_t(p.rows) * O);
-        }
-      };
-      std::vector<std::thread> pool;
-      for (int t = 1; t < helpers; ++t) pool.emplace_back(copy_share, t);
-      copy_share(0);
-      for (auto &th : pool) th.join();
-    }
-    for (const Piece &p : sl.pieces)
-      if (p.last || status) complete_ticket(s, p.ticket, status);
-    {
-      std::lock_guard<std::mutex> lk(s->qmu);
+    std::unique_lock<std::mutex> lk(s->qmu);
+    if (e != hipSuccess) {  // the batch is lost: fail its tickets, free the slot
+      for (Piece &p : sl.pieces) {
+        p.state = 3;
+        auto it = s->pending.find(p.ticket);
+        if (it != s->pending.end()) it->second.status = FDNN_E_DEVICE;
+      }
+      sl.pieces_left = 0;
       sl.in_flight = false;
+      s->slot_cv.notify_all();
+      s->done_cv.notify_all();
+      continue;
     }
-    s->slot_cv.notify_all();
+    for (Piece &p : sl.pieces) p.state = 1;
+    s->done_cv.notify_all();             // callers blocked in wait() copy their own rows ...
+    copy_ready_pieces(s, lk, sl, 0);     // ... and this thread takes whatever nobody has claimed
   }
 }
 
@@ -387,7 +422,6 @@ void fdnn_server_free(fdnn_server *s) {
   for (Slot &sl : s->slots) {
     if (sl.ctx) fdnn::destroy_ctx(sl.ctx);
     if (sl.h_x) hipHostFree(sl.h_x);
-    if (sl.h_out) hipHostFree(sl.h_out);
     if (sl.h_mask) hipHostFree(sl.h_mask);
     if (sl.d_out) hipFree(sl.d_out);
     if (sl.gemm_done) hipEventDestroy(sl.gemm_done);
@@ -463,7 +497,7 @@ int fdnn_server_submit(fdnn_server *s, const float *x, int n, const int8_t *mask
   }
   {
     std::lock_guard<std::mutex> lk(s->qmu);
-    s->pending.emplace(t, 0);
+    s->pending.emplace(t, TicketState{});
     s->queue.push_back(Request{t, x, masks, out, n, 0});
   }
   s->n_requests++;
@@ -476,17 +510,27 @@ int fdnn_server_wait(fdnn_server *s, uint64_t ticket) {
   if (!s) return fail(FDNN_E_ARG, "null argument");
   {  // a host ticket?
     std::unique_lock<std::mutex> lk(s->qmu);
-    auto it = s->pending.find(ticket);
-    if (it != s->pending.end()) {
-      s->done_cv.wait(lk, [&] {
-        auto j = s->pending.find(ticket);
-        return j == s->pending.end() || j->second != 0;
-      });
-      auto j = s->pending.find(ticket);
-      if (j == s->pending.end()) return FDNN_OK;
-      const int status = j->second;
-      s->pending.erase(j);
-      return fail(status, "a batch carrying this ticket failed on the device");
+    if (s->pending.find(ticket) != s->pending.end()) {
+      for (;;) {
+        auto it = s->pending.find(ticket);
+        if (it == s->pending.end()) return FDNN_OK;  // complete (the last piece was copied, here or by the finisher)
+        if (it->second.status != 0) {
+          const int status = it->second.status;
+          s->pending.erase(it);
+          return fail(status, "a batch carrying this ticket failed on the device");
+        }
+        bool copied = false;
+        for (Slot &sl : s->slots) {
+          if (!sl.in_flight) continue;
+          for (const Piece &p : sl.pieces)
+            if (p.ticket == ticket && p.state == 1) {
+              copy_ready_pieces(s, lk, sl, ticket);
+              copied = true;
+              break;
+            }
+        }
+        if (!copied) s->done_cv.wait(lk);
+      }
     }
   }
   hipEvent_t ev = nullptr;
@@ -508,7 +552,7 @@ int fdnn_server_drain(fdnn_server *s) {
     std::unique_lock<std::mutex> lk(s->qmu);
     s->done_cv.wait(lk, [&] {
       for (const auto &kv : s->pending)
-        if (kv.second == 0) return false;
+        if (kv.second.status == 0) return false;
       return true;
     });
   }
