@@ -203,7 +203,9 @@ void packer_loop(fdnn_server *s) {
     std::unique_lock<std::mutex> lk(s->qmu);
     s->qcv.wait(lk, [&] { return s->stop || !s->queue.empty(); });
     if (s->stop && s->queue.empty()) return;
-    if (s->linger_us > 0 && !s->stop) {  // give concurrent callers a moment to join the batch
+    bool gpu_busy = false;  // lingering only pays while an earlier batch keeps the device busy: an idle server launches at once
+    for (const Slot &sl : s->slots) gpu_busy |= sl.in_flight;
+    if (s->linger_us > 0 && !s->stop && gpu_busy) {  // give concurrent callers a moment to join the batch
       size_t have = 0;
       for (const Request &r : s->queue) have += size_t(r.n - r.taken);
       if (have < size_t(s->max_frames))

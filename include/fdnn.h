@@ -164,7 +164,8 @@ FDNN_API int fdnn_ctx_read_hidden(fdnn_ctx *c, uint8_t *out);
  *     coalesced utterance is bit-identical to the same utterance scored alone
  *     (frames are independent, kernels are batch-size invariant).
  *   fdnn_server_set_linger_us  how long the packer waits for more host
- *     submissions before launching a batch that is not full (default 0).
+ *     submissions before launching a batch that is not full (default 0); it
+ *     never lingers while the server is idle (no batch in flight).
  *   fdnn_model_enable_batcher  routes fdnn_calculate (= the JNI calculate()) of
  *     this model through an internal server, so that the unmodified Java class
  *     called from many threads is coalesced as well; also switched on at load by
