@@ -144,8 +144,10 @@ def main() -> None:
     # defaults: ~0.2 s of GPU time per pass; short runs (20 steps) read low without the clock ramp below
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU,
-                    help="frames per GPU per step (BASELINE configs[4] = 1 M frames over 8 GPUs: --gpus 8 --frames 125000)")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="frames per GPU per step; default 10 000 on one GPU (BASELINE configs[2]) and 125 000 on several "
+                         "(configs[4]: 1 M frames over 8 GPUs) -- the per-frame rate is the same at both sizes, large batches run "
+                         "as 10 240-frame chunks")
     ap.add_argument("--mode", default="gauss", choices=["gauss", "nosat"], help="synthetic weight distribution")
     ap.add_argument("--in-flight", type=int, default=2, help="steps in flight in the scoring loop (1 = no overlap between steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -186,7 +188,7 @@ def main() -> None:
         F.ensure_model_file(model_path, F.NET_TOPOLOGY, seed=1, mode=args.mode)
     dnn = load_replicated(model_path, local, rank, world)
     O = dnn.outputDimension()
-    n = args.frames
+    n = args.frames if args.frames > 0 else (FRAMES_PER_GPU if world == 1 else 125000)
     depth = max(1, args.in_flight)
     if args.l0_fma:
         dnn.setInputLayerFma(True)
@@ -444,8 +446,8 @@ def main() -> None:
             "dtype": "int8 (u8 activations x s8 weights -> int32; fp32 layer 0 and soft-max)",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[2]: synthetic Kaldi nnet 432 -> 7x2048 -> 8000 ({args.mode} weights, seed 1), "
-                            f"{n}-frame batch per GPU, full soft-max, device-resident in/out",
+                "workload": f"BASELINE {'configs[2]' if world == 1 else 'configs[4]'}: synthetic Kaldi nnet 432 -> 7x2048 -> 8000 "
+                            f"({args.mode} weights, seed 1), {n}-frame batch per GPU, full soft-max, device-resident in/out",
                 "frames_per_gpu": n, "global_frames": world * n, "parallelism": f"frame-sharded x{world}, replicated weights",
                 "layer0_numerics": "fused (reference built -march=native)" if args.l0_fma else "unfused (reference built -msse4, canonical)",
                 "steps_in_flight": depth,

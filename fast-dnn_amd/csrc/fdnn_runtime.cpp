@@ -396,6 +396,21 @@ int acquire_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
 // the context's last enqueued work and ends by recording it: calculateUntilOutputDevice(stream)
 // followed by calculateForOutputNodes() or hiddenActivations() reads finished activations
 // without the caller synchronising anything.  On one stream both calls are no-ops for the device.
+std::vector<std::pair<int, int>> frame_chunks(int n) {
+  std::vector<std::pair<int, int>> out;
+  if (n <= kChunkFrames + kChunkFrames / 2) {
+    out.emplace_back(0, n);
+    return out;
+  }
+  int off = 0;
+  while (n - off > kChunkFrames + kChunkFrames / 4) {  // a tail of up to a quarter chunk rides with the last full one
+    out.emplace_back(off, kChunkFrames);
+    off += kChunkFrames;
+  }
+  out.emplace_back(off, n - off);
+  return out;
+}
+
 hipError_t ctx_enter(fdnn_ctx *c, hipStream_t s) {
   if (c->done_valid && c->done_stream == s) return hipSuccess;  // same stream: already in order
   return hipStreamWaitEvent(s, c->done, 0);
@@ -761,12 +776,20 @@ int fdnn_calculate_device(fdnn_model *m, const float *d_x, int n, float *d_out, 
   DeviceGuard g(m->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   fdnn_ctx *c = nullptr;
-  int rc = acquire_ctx(m, n, &c);
+  const auto chunks = fdnn::frame_chunks(n);
+  int cap = 0;  // the scratch only has to hold the largest chunk
+  for (const auto &ch : chunks) cap = std::max(cap, ch.second);
+  int rc = acquire_ctx(m, cap, &c);
   if (rc) return rc;
   const hipError_t e = ctx_enter(c, s);
   if (e == hipSuccess) {
-    rc = run_hidden(c, d_x, s, nullptr);
-    if (!rc) rc = run_output(c, 0, n, nullptr, d_out, s, nullptr);
+    const size_t D = size_t(m->hm.hdr.in_dim), O = size_t(m->hm.hdr.out_dim);
+    for (const auto &ch : chunks) {  // frames are independent: a chunk is a batch of its own
+      c->n = ch.second;
+      rc = run_hidden(c, d_x + size_t(ch.first) * D, s, nullptr);
+      if (!rc) rc = run_output(c, 0, ch.second, nullptr, d_out + size_t(ch.first) * O, s, nullptr);
+      if (rc) break;
+    }
   }
   release_ctx(c, s);  // also on the error paths: the context goes back to the pool
   if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("fdnn_calculate_device: ") + hipGetErrorString(e));

@@ -71,7 +71,7 @@ struct Request {
 struct Slot {
   fdnn_ctx *ctx = nullptr;
   hipStream_t stream = nullptr;   // small batches: the whole batch; host batches: copies
-  hipEvent_t gemm_done = nullptr, staged = nullptr, done = nullptr;
+  hipEvent_t gemm_done = nullptr, tail_done = nullptr, staged = nullptr, done = nullptr;
   uint64_t ticket = 0;            // device submissions: the ticket this slot last carried
   bool used = false;              // `done` has been recorded at least once
   // host submissions (allocated on first use)
@@ -136,15 +136,31 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
   hipStream_t cs = small ? sl.stream : s->s_main;
   if (after) HIP_TRY(hipStreamWaitEvent(cs, after, 0));
   HIP_TRY(fdnn::ctx_enter(c, cs));
-  int rc = fdnn::run_hidden(c, d_x, cs, nullptr);
+  int rc = FDNN_OK;
   hipStream_t end = cs;
-  if (!rc) {
-    if (small) {
-      rc = fdnn::run_output(c, 0, n, d_masks, d_out, cs, nullptr);
-    } else {
-      rc = fdnn::run_output(c, 0, n, d_masks, d_out, cs, nullptr, nullptr, s->s_tail, sl.gemm_done);
-      end = s->s_tail;
+  if (small) {
+    rc = fdnn::run_hidden(c, d_x, cs, nullptr);
+    if (!rc) rc = fdnn::run_output(c, 0, n, d_masks, d_out, cs, nullptr);
+  } else {
+    // very large batches go chunk by chunk (fdnn::frame_chunks), and the chunks overlap like batches do: chunk j's
+    // scale pass runs on the tail stream under chunk j+1's layer 0.  One context serves all chunks, so the compute
+    // stream may not overwrite the soft-max partial sums (chunk j+1's output GEMM) before chunk j's scale pass has
+    // read them: it waits for `tail_done` there.
+    const size_t D = size_t(s->m->hm.hdr.in_dim), O = size_t(s->m->hm.hdr.out_dim);
+    bool first = true;
+    for (const auto &ch : fdnn::frame_chunks(n)) {
+      c->n = ch.second;
+      rc = fdnn::run_hidden(c, d_x + size_t(ch.first) * D, cs, nullptr);
+      if (rc) break;
+      if (!first) HIP_TRY(hipStreamWaitEvent(cs, sl.tail_done, 0));
+      rc = fdnn::run_output(c, 0, ch.second, d_masks ? d_masks + size_t(ch.first) * O : nullptr, d_out + size_t(ch.first) * O, cs,
+                            nullptr, nullptr, s->s_tail, sl.gemm_done);
+      if (rc) break;
+      HIP_TRY(hipEventRecord(sl.tail_done, s->s_tail));
+      first = false;
     }
+    c->n = n;
+    end = s->s_tail;
   }
   fdnn::ctx_leave(c, end);
   if (rc) return rc;
@@ -392,6 +408,7 @@ int fdnn_server_create(fdnn_model *m, int max_frames, int depth, fdnn_server **o
     if (rc) break;
     e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.gemm_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.tail_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.staged, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
   }
@@ -427,6 +444,7 @@ void fdnn_server_free(fdnn_server *s) {
     if (sl.h_mask) hipHostFree(sl.h_mask);
     if (sl.d_out) hipFree(sl.d_out);
     if (sl.gemm_done) hipEventDestroy(sl.gemm_done);
+    if (sl.tail_done) hipEventDestroy(sl.tail_done);
     if (sl.staged) hipEventDestroy(sl.staged);
     if (sl.done) hipEventDestroy(sl.done);
     if (sl.stream) hipStreamDestroy(sl.stream);

@@ -196,3 +196,46 @@ def test_host_and_device_submissions_share_one_server(mid_model_path):
         assert np.array_equal(out, want[i]), (w, j)
     srv.close()
     dnn.delete()
+
+
+def test_very_large_batches_run_in_chunks(mid_model_path):
+    """Dense passes over more than 15 360 frames run as 10 240-frame chunks (fdnn::frame_chunks) --
+    back to back in fdnn_calculate_device, overlapped through the tail stream in the scoring loop,
+    with and without masks.  Frames around every chunk boundary against the oracle, and the three
+    paths against each other bit for bit."""
+    import torch
+
+    n, O = 33000, 1000   # chunks 10240 + 10240 + 12520
+    x = F.synth_features(n, 432, seed=77)
+    idx = np.array([0, 1, 10238, 10239, 10240, 10241, 20478, 20479, 20480, 20481, 32998, 32999])
+    orc = Oracle(mid_model_path)
+    want = orc.calculate(x[idx])
+    dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+    xd = torch.from_numpy(x).cuda()
+    a = torch.zeros((n, O), dtype=torch.float32, device="cuda")
+    dnn.calculate_device(xd.data_ptr(), n, a.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert np.abs(a[torch.from_numpy(idx).cuda()].cpu().numpy() - want).max() <= TIGHT
+    assert float((a.sum(1) - 1).abs().max()) < 1e-4
+    # unchunked reference: the same frames in pieces below the chunking threshold
+    b = torch.zeros_like(a)
+    for lo in range(0, n, 11000):
+        hi = min(n, lo + 11000)
+        dnn.calculate_device(xd[lo:hi].data_ptr(), hi - lo, b[lo:hi].data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    srv = api.ScoringServer(dnn, n, 2)
+    c1, c2 = torch.zeros_like(a), torch.zeros_like(a)
+    t1 = srv.submit_device(xd.data_ptr(), n, c1.data_ptr())
+    t2 = srv.submit_device(xd.data_ptr(), n, c2.data_ptr())
+    srv.wait(t1)
+    srv.wait(t2)
+    assert torch.equal(c1, a) and torch.equal(c2, a)
+    masks = torch.from_numpy(F.generate_masks_fast(n, O, 0.4, 0.03, seed=3)).cuda()
+    lz = torch.zeros_like(a)
+    srv.wait(srv.submit_device(xd.data_ptr(), n, lz.data_ptr(), masks.data_ptr()))
+    sel = torch.from_numpy(idx).cuda()
+    want_lazy = orc.lazy(x[idx], masks[sel].cpu().numpy())
+    assert np.abs(lz[sel].cpu().numpy() - want_lazy).max() <= TIGHT
+    srv.close()
+    dnn.delete()
