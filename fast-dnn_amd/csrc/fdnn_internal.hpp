@@ -109,9 +109,9 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps);
 int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out, hipStream_t s, const Taps *taps,
                float *d_final = nullptr, hipStream_t tail = nullptr, hipEvent_t gemm_done = nullptr);
 // A dense pass over a very large batch runs as chunks of kChunkFrames frames (32 frame tiles of 320: one
-// workgroup per CU in the hidden layers): a chunk's 320 MB of exp(z) rows are re-read by its soft-max scale while
-// much of them still sits in the 256 MB Infinity Cache, which a 125 000-frame batch (4 GB of rows) loses --
-// measured 10.1 M frames/s unchunked against 10.8 M for 10 000-frame batches on the same box.  Returns
+// workgroup per CU in the hidden layers): a chunk's 320 MB of exp(z) rows are written and re-read by its soft-max
+// scale within a working set the 256 MB Infinity Cache and the translation caches largely cover, which a
+// 125 000-frame batch (4 GB of rows) is not -- measured 10.1 M frames/s unchunked against 11.4 M chunked.  Returns
 // (offset, count) pairs; batches up to 1.5 chunks stay whole, a short tail joins the previous chunk.
 constexpr int kChunkFrames = 10240;
 std::vector<std::pair<int, int>> frame_chunks(int n);
