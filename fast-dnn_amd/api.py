@@ -93,6 +93,7 @@ SIGNATURES = {
     "fdnn_model_export_blob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fdnn_model_import_blob": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
     "fdnn_debug_forward_taps": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_i8p, _c_f32p, _c_u8p, _c_i32p, _c_i32p, _c_f32p, _c_f32p]),
+    "fdnn_debug_layer0": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_u8p, C.POINTER(C.c_ulonglong)]),
     "fdnn_profile_begin": (C.c_int, [C.c_void_p]),
     "fdnn_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "fdnn_host_model_load": (C.c_int, [C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),
@@ -446,6 +447,14 @@ class QuantizedDnn:
         cnt = (C.c_int * 5)()
         _check(lib().fdnn_profile_end(self.nativeDnnHandle, ms, cnt))
         return {k: {"ms": float(ms[i]), "launches": int(cnt[i])} for i, k in enumerate(self.PROF_KINDS)}
+
+    def layer0(self, input):
+        """Layer 0 alone through the production kernels: (u8 [n][hidden], outputs recomputed exactly)."""
+        x = _f32(input)
+        out = np.empty((x.shape[0], self.hiddenDimension()), dtype=np.uint8)
+        rec = C.c_ulonglong()
+        _check(lib().fdnn_debug_layer0(self.nativeDnnHandle, x.ctypes.data_as(_c_f32p), x.shape[0], out.ctypes.data_as(_c_u8p), C.byref(rec)))
+        return out, int(rec.value)
 
     # -- parity taps ----------------------------------------------------------
     def forwardTaps(self, input, masks=None) -> dict:

@@ -44,6 +44,8 @@ struct fdnn_model {
   int device = 0;
   uint8_t *d_blob = nullptr;
   float *d_w0t = nullptr;  // layer-0 weights as a chain-major image [4][l0_j_pad][l0_h_ld] (fdnn_l0.hip)
+  float *d_w0norm = nullptr;  // [H] ||w_n||_2 rounded up: the node half of the screened layer-0 path's bound
+  unsigned long long *d_l0_stats = nullptr;  // [2] screened-path counters (outputs recomputed exactly at [1])
   int l0_jc = 0, l0_j_pad = 0, l0_h_ld = 0;
   int l0_fma = 0;
   int l0_kernel = 0;  // fdnn_debug_set_l0_kernel
@@ -73,12 +75,18 @@ struct fdnn_ctx {
   float *d_xt = nullptr;          // [4][l0_j_pad][xt_ld] layer-0 frame image (shifted, scaled, chain-major)
   int xt_ld = 0;
   float *d_l0park = nullptr;      // [xt_ld][l0_h_ld] partial chain sums parked by the layer-0 kernel
+  float *d_xnorm = nullptr;       // [cap] frame norms of the screened layer-0 path
+  uint32_t *d_scr_count = nullptr;  // [frame tiles x node tiles] flagged outputs per tile (kept zero between launches)
+  uint16_t *d_scr_list = nullptr;   // [tiles][kL0ScreenCap]
   int8_t *d_act[2] = {nullptr, nullptr};  // [n_pad][act_ld] ping/pong, s8 = u8-128
   float *d_out = nullptr;         // [n][O]
   float *d_partial = nullptr;     // [rows_pad/64][n_pad]
   int8_t *d_mask = nullptr;       // [n][O]
   int last = -1;                  // d_act index holding the last hidden layer, -1 = not computed
   bool pooled = false;
+  bool l0_chain_only = false;     // scoring loop, large batches: the soft-max scale of the previous batch runs under this
+                                  // batch's layer 0, which must then be the vector-pipe chain kernel (the matrix-pipe
+                                  // screened path fills the register file: nothing can run beside it)
   // per-frame lazy calls (the JNI contract): host-mapped pinned staging for kPinFrames masks and
   // result rows -- the output kernel reads the mask and the scale kernel writes the probabilities
   // straight through these, so a call is two launches and one stream sync, no copy commands

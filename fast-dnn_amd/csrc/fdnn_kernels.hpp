@@ -30,7 +30,16 @@ struct L0Params {
   float *park;         // [n_ld/128][h_ld/128][64 KB] scratch: l2 + l3 of a tile while l0, l1 run (128-node tiles only, else null)
   int j_pad, jc;       // D/4 rounded up to the chunk depth jc = l0_chunk_rows(D)
   int n_ld, h_ld;      // image row lengths: frame capacity and H, both rounded up to 128
+  // canonical flavour, screened path (large batches, no taps): the FUSED chains on the fp32 MFMA for every output,
+  // a rigorous bound on |fused - unfused| per output, and the exact unfused chains for the few outputs whose
+  // table index the difference could change (fdnn_l0.hip: "screened").  All null/0 = path not available.
+  float *xnorm;        // [n] scratch: upper bound of ||(x_f + shift) * scale||_2
+  const float *wnorm;  // [H] upper bound of ||w_n||_2 (model load)
+  uint32_t *scr_count; // [tiles] flagged outputs per 128 x 128 tile; zero between launches
+  uint16_t *scr_list;  // [tiles][kL0ScreenCap] tile-local indices frame_row * 128 + node_col
+  unsigned long long *scr_stats;  // [2] running totals: outputs screened, outputs recomputed (may be null)
 };
+constexpr int kL0ScreenCap = 4096;  // listed outputs per tile (25 %); a tile that overflows is recomputed whole
 void launch_l0(const L0Params &p, hipStream_t s);
 int l0_chunk_rows(int D);
 int l0_chain_node_tile();  // 64 (default: no park scratch needed) or 128 (L0Params::park must be allocated)

@@ -216,6 +216,9 @@ typedef float v32f __attribute__((ext_vector_type(32)));
 #ifndef FDNN_L0_SCHED_MASK
 #define FDNN_L0_SCHED_MASK 0x3f4  // what may cross the products | adds fence of the chain kernel: memory and scalar ops
 #endif
+#ifndef FDNN_L0_SCREEN_EVERY
+#define FDNN_L0_SCREEN_EVERY 2  // screened path: the fused partial sums are sampled every this many 8-step chunks
+#endif
 #ifndef FDNN_L0_TN64_WAVES
 #define FDNN_L0_TN64_WAVES 3  // waves per SIMD the 64-node chain kernel is compiled for (134 VGPRs as written)
 #endif
@@ -501,7 +504,29 @@ struct L0MfmaCfg {
   static_assert(XPT >= 1 && XPT * RPQ == TF && WPT * RPQ == TN, "chunk does not divide over the threads");
 };
 
-template <int BK, int WFR, bool TAP>
+// SCREEN (canonical flavour on the matrix pipe): the reference's canonical numerics round every product and every
+// add (dnn.cc:233-238); this kernel's chains round once per step (fma).  The two agree to a few ulp, and the layer's
+// OUTPUT is only the 8-bit table entry of round(100 * lin): so the fused result is used wherever the difference
+// provably cannot move 100 * lin across a rounding boundary of the table index, and the handful of outputs where it
+// could are listed for l0_fix_kernel, which recomputes them with the exact unfused chains.
+//
+// Bound (u = 2^-24; t_k = x_k * w_k exact; S = sum_k |t_k| over all four chains; s_j the computed partial sums):
+//   fused chain    s_j  = fl(s_{j-1} + t_j)              =>  s_n  - sum t = sum_j eps_j,            |eps_j| <= u |s_j| / (1-u)
+//   unfused chain  s'_j = fl(s'_{j-1} + fl(t_j))         =>  s'_n - sum t = sum_j eps'_j + sum_j rho_j, |rho_j| <= u |t_j|
+//   (telescoping, exact).  The kernel samples the fused partial sums at the start of every window of W = 8 kScreenEvery
+//   steps: inside a window |s_j| <= |s_start| + S_window, so  sum_j |s_j| <= W A + W S  with  A = sum over windows and chains of
+//   |s_start|  (accumulated in registers; the kernel keeps one A per frame row and pair of node columns: an upper bound of
+//   each), and |s'_j| <= |s_j| + 218 u S  (the classical gamma_n bound).  Hence
+//     |lin_fused - lin_unfused| <= E = 1.0002 u (2W A + (2W + 1) S + 8 (F + |bias|)),
+//   the last term for the three adds of (l0+l1)+(l2+l3) and the bias add (the same operations on both sides, each can
+//   widen the gap by one rounding of a value <= F + |bias|, F = sum of the four final |chain values|), and S <=
+//   ||x||_2 ||w||_2 (Cauchy-Schwarz, both norms rounded up).  |fl(100 lin) - fl(100 lin')| <= D = 100.001 E + 4 u |fl(100 lin)|;
+//   round() can differ only if a half-integer lies within D of fl(100 lin) (ties included): those outputs are flagged --
+//   unless both neighbouring indices hold the same table byte.  Products below 2^-126 add at most 432 * 2^-150, covered by
+//   the 1e-30 in D; a NaN anywhere flags.  (With the classical bound 218 u S alone 1.9 % of the outputs were flagged;
+//   A is small because partial sums are random-walk sized, S is not.)
+constexpr int kScreenEvery = FDNN_L0_SCREEN_EVERY;
+template <int BK, int WFR, bool TAP, bool SCREEN = false>
 __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using Cfg = L0MfmaCfg<BK, WFR>;
@@ -571,9 +596,34 @@ __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
   gload(0);
   lstore(0);
   __syncthreads();
+  // SCREEN: A of the bound above.  One register per frame row of this lane, shared by its two node columns (the sum
+  // over both columns bounds each: 16 registers instead of 32 -- with 32 the k-loop spilled).
+  float absacc[SCREEN ? 16 : 1];
+  if (SCREEN) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) absacc[SCREEN ? r : 0] = 0.0f;
+  }
   for (int c = 0; c < nchunk; ++c) {
     const int buf = c & 1;
     if (!(FDNN_L0_DEBUG & 2) && c + 1 < nchunk) gload(c + 1);
+    if (SCREEN && c > 0 && c % kScreenEvery == 0) {  // the chains' partial sums at the start of this window (zero before the first)
+      // fenced: left to itself the scheduler overlaps these reads with the next MFMAs by copying the accumulators they
+      // are about to overwrite (289 spilled registers)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // eight in-place v_add_f32 with |.| on the accumulator operand (written as asm: through fabsf() the compiler
+        // copied the four 32-register accumulator tuples before reading them)
+        float a = absacc[SCREEN ? r : 0];
+#pragma unroll
+        for (int sc = 0; sc < 4; ++sc) {
+          asm volatile("v_add_f32 %0, |%1|, %0" : "+v"(a) : "v"(acc[sc >> 1][sc & 1][r]));
+          asm volatile("v_add_f32 %0, |%1|, %0" : "+v"(a) : "v"(acc[sc >> 1][sc & 1][16 + r]));
+        }
+        absacc[SCREEN ? r : 0] = a;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     const float *xb = smem + buf * kStage + (wf * 32 + l32) * LD + 2 * h;
     const float *wb = smem + buf * kStage + (TF + wn * 64 + l32) * LD + 2 * h;
     // a zero-filled tail quad adds fma(0, 0, acc) = acc
@@ -602,12 +652,26 @@ __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
   // epilogue: combine the chains, bias, table; bytes go through LDS so that each frame
   // row leaves as one 128-B segment
   uint8_t *tile = reinterpret_cast<uint8_t *>(smem);
+  // SCREEN: the tile's list of flagged outputs lives behind the byte tile (TF * TS bytes) in the dead staging ring
+  uint32_t *scr_n = reinterpret_cast<uint32_t *>(tile + TF * TS);
+  uint16_t *scr_l = reinterpret_cast<uint16_t *>(tile + TF * TS + 16);
+  static_assert(!SCREEN || TF * TS + 16 + 2 * kL0ScreenCap <= 2 * kStage * 4, "flag list must fit in the staging ring");
+  if (SCREEN) {
+    if (tid == 0) *scr_n = 0;
+    __syncthreads();
+  }
+  // SCREEN, pass 1 (branch free): one flag bit per output of this lane (bit 16 s + r).  The frame norms of the lane's
+  // 16 rows are fetched once.
+  uint32_t scr_mask = 0;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int col = wn * 64 + s * 32 + l32;
     const int node = n0 + col;
     const float bias = node < p.H ? p.bias[node] : 0.0f;
+    const float wn_bound = (SCREEN && node < p.H) ? p.wnorm[node] : 0.0f;
+    constexpr float kScreenE = 1.0002f * 5.9604645e-8f, kScreenT = 4.0f * 5.9604645e-8f;  // 1.0002 u (covers 1/(1-u) and float evaluation of E), 4 u
     uint8_t act[16];  // table gathers first, tile writes after: the two alias in LDS as far as the compiler knows
+    uint8_t nb0[16], nb1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wf * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
@@ -616,11 +680,69 @@ __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
       const float lin = sum + bias;
       if (TAP && f0 + row < p.n && node < p.H) p.tap_lin[static_cast<size_t>(f0 + row) * p.H + node] = lin;
       act[r] = lut[lut_index(lin)];
+      if (SCREEN) {  // the table bytes on both sides of the half-integer nearest to 100 lin
+        const float t = lin * 100.0f;
+        const float fl = floorf(t);
+        const int lo = fabsf(t) < 1.0e6f ? static_cast<int>(fl) : 0;
+        nb0[r] = lut[max(-kLutHalf, min(kLutHalf, lo)) + kLutHalf];
+        nb1[r] = lut[max(-kLutHalf, min(kLutHalf, lo + 1)) + kLutHalf];
+      }
+    }
+    if (SCREEN) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wf * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+        const float t = (((acc[s][0][r] + acc[s][0][16 + r]) + (acc[s][1][r] + acc[s][1][16 + r])) + bias) * 100.0f;  // as above
+        const float xn = f0 + row < p.n ? p.xnorm[f0 + row] : 0.0f;
+        const float F = (fabsf(acc[s][0][r]) + fabsf(acc[s][0][16 + r])) + (fabsf(acc[s][1][r]) + fabsf(acc[s][1][16 + r]));
+        constexpr float kW = 2.0f * (BK / 4) * kScreenEvery;  // 2 x steps per window: both chains' partial sums
+        const float E = fmaf(kW, absacc[SCREEN ? r : 0], fmaf((kW + 1.0f) * xn, wn_bound, 8.0f * (F + fabsf(bias)))) * kScreenE;
+        const float D = fmaf(100.001f, E, fabsf(t) * kScreenT) + 1e-30f;
+        const float fr = fabsf((t - floorf(t)) - 0.5f);  // distance to the nearest half-integer (exact below 2^23)
+        const bool near = !(fr > D) && !(fabsf(t) - D >= 641.0f);     // written so that a NaN flags
+        const bool one_boundary = D < 0.25f && fabsf(t) < 1.0e6f;     // else: several boundaries in reach, always recompute
+        const bool flag = near && !(one_boundary && nb0[r] == nb1[r]) && f0 + row < p.n && node < p.H;
+        scr_mask |= flag ? (1u << (16 * s + r)) : 0u;
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) tile[(wf * 32 + 8 * (r >> 2) + 4 * h + (r & 3)) * TS + col] = act[r];
   }
+  if (SCREEN) {
+    // pass 2: the wave reserves room for all its flagged outputs with ONE LDS atomic, every lane then writes its own
+    // entries (a push per output cost an atomic round trip in 3 of 4 loop iterations: 413 us instead of 188)
+    const int mine = __popc(scr_mask);
+    int incl = mine;  // inclusive prefix sum over the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    const int wave_total = __shfl(incl, 63);
+    uint32_t base = 0;
+    if (wave_total) {
+      if (lane == 63) base = atomicAdd(scr_n, static_cast<uint32_t>(wave_total));
+      base = __shfl(base, 63);
+      uint32_t at = base + static_cast<uint32_t>(incl - mine);
+      uint32_t m = scr_mask;
+      while (m) {
+        const int i = __ffs(m) - 1;
+        m &= m - 1;
+        const int r = i & 15, sb = i >> 4;
+        const int row = wf * 32 + 8 * (r >> 2) + 4 * h + (r & 3), col = wn * 64 + sb * 32 + l32;
+        if (at < static_cast<uint32_t>(kL0ScreenCap)) scr_l[at] = static_cast<uint16_t>(row * TN + col);
+        ++at;
+      }
+    }
+  }
   __syncthreads();
+  if (SCREEN) {
+    const int tile_id = by * ((p.H + TN - 1) / TN) + bx;
+    const uint32_t cnt = *scr_n;
+    if (tid == 0) p.scr_count[tile_id] = cnt;  // > kL0ScreenCap: the fix kernel recomputes the whole tile
+    const uint32_t listed = min(cnt, static_cast<uint32_t>(kL0ScreenCap));
+    for (uint32_t i = tid; i < listed; i += THREADS) p.scr_list[static_cast<size_t>(tile_id) * kL0ScreenCap + i] = scr_l[i];
+  }
 #pragma unroll
   for (int q = 0; q < TF * 8 / THREADS; ++q) {
     const int item = tid + q * THREADS, row = item >> 3, c16 = (item & 7) * 16;
@@ -630,6 +752,111 @@ __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
           *reinterpret_cast<const uint4 *>(tile + row * TS + c16);
   }
 #endif
+}
+
+// ||(x_f + shift) * scale||_2 per frame, rounded UP (one wave per frame): the frame half of the screened path's bound.
+__global__ __launch_bounds__(256) void l0_xnorm_kernel(const float *x, const float *shift, const float *scale, float *xnorm, int n, int D) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (f >= n) return;
+  float s = 0.0f;
+  for (int k = 4 * lane; k < D; k += 256) {  // D is a multiple of 4
+    const v4f v = (*reinterpret_cast<const v4f *>(x + static_cast<size_t>(f) * D + k) + *reinterpret_cast<const v4f *>(shift + k)) *
+                  *reinterpret_cast<const v4f *>(scale + k);
+    s = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, s))));
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  // the float (fma) sum of D squares is within D u of the true one, the square root and the shuffles' adds a few u more:
+  // rounded up by (1 + 2 D u + 1e-5)  (D <= 2^20 by the loader)
+  if (lane == 0) xnorm[f] = sqrtf(s) * (1.00001f + 2.0f * 5.9604645e-8f * static_cast<float>(D));
+}
+
+// element `src` (0..3) of every aligned group of four lanes, to all four: a DPP quad_perm move, no LDS traffic
+template <int SRC>
+__device__ __forceinline__ float quad_bcast(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), SRC * 0x55, 0xf, 0xf, true));
+}
+
+// The exact canonical chains (four k-mod-4 partial sums, multiply and add rounded separately, (l0+l1)+(l2+l3), bias,
+// table: dnn.cc:219-286) for the outputs l0_mfma_kernel<SCREEN> listed -- all 128 x 128 of them when a tile's list
+// overflowed.  One 256-thread workgroup per tile, FOUR lanes per listed output: lane c is chain c.  The four lanes walk
+// the two operand rows 64 contiguous bytes per load instruction -- lane c fetches the quad of k-step 4i + c (x with shift
+// and scale applied, w) -- and each step's quad is then handed round with quad broadcasts, chain c keeping element c.
+// (One lane per output reading 16 bytes of its own rows per load is address-processing bound: every (output, k-quad) is
+// its own 16-byte segment -- 66 us for 0.4 % of the outputs.)
+__global__ __launch_bounds__(256) void l0_fix_kernel(L0Params p) {
+  constexpr int TF = 128, TN = 128;
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const int node_tiles = (p.H + TN - 1) / TN;
+  const int tile_id = blockIdx.x, by = tile_id / node_tiles, bx = tile_id % node_tiles;
+  const uint32_t count = p.scr_count[tile_id];
+  if (count == 0) return;
+  const int f0 = by * TF, n0 = bx * TN;
+  const bool all = count > static_cast<uint32_t>(kL0ScreenCap);
+  const int total = all ? TF * TN : static_cast<int>(count);
+  const int tid = threadIdx.x, c = tid & 3;
+  const int quads = p.D / 4;  // D is a multiple of 4
+  extern __shared__ __attribute__((aligned(16))) float fix_smem[];  // shift[D], scale[D]
+  float *sh_s = fix_smem, *sc_s = fix_smem + p.D;
+  for (int k = tid; k < p.D; k += 256) {
+    sh_s[k] = p.shift[k];
+    sc_s[k] = p.scale[k];
+  }
+  __syncthreads();
+  int done = 0;
+  for (int base = 0; base < total; base += 64) {  // (uniform trip count: the quad broadcasts need all four lanes present)
+    const int o = base + (tid >> 2);
+    const bool valid = o < total;
+    const int local = valid ? (all ? o : p.scr_list[static_cast<size_t>(tile_id) * kL0ScreenCap + o]) : 0;
+    const int f = f0 + local / TN, node = n0 + local % TN;
+    const bool live = valid && f < p.n && node < p.H;
+    const float *xr = p.x + static_cast<size_t>(live ? f : 0) * p.D, *wr = p.w + static_cast<size_t>(live ? node : 0) * p.D;
+    float acc = 0.0f;
+    // twelve k-steps per round: the three quads per lane (and operand) are all requested before the first is used --
+    // with one quad in flight per lane the walk is a chain of 27 L2 round trips
+    for (int q0 = 0; q0 < quads; q0 += 12) {
+      v4f xq[3], wq[3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int q = min(q0 + 4 * b + c, quads - 1);  // (a clamped quad is never consumed: its step is skipped below)
+        xq[b] = *reinterpret_cast<const v4f *>(xr + 4 * q);
+        wq[b] = *reinterpret_cast<const v4f *>(wr + 4 * q);
+      }
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int q = min(q0 + 4 * b + c, quads - 1);
+        xq[b] = (xq[b] + *reinterpret_cast<const v4f *>(sh_s + 4 * q)) * *reinterpret_cast<const v4f *>(sc_s + 4 * q);  // add, then multiply
+      }
+#define FDNN_FIX_STEP(B, S)                                                                                                   \
+  if (q0 + 4 * B + S < quads) {                                                                                               \
+    const float x0 = quad_bcast<S>(xq[B].x), x1 = quad_bcast<S>(xq[B].y), x2 = quad_bcast<S>(xq[B].z), x3 = quad_bcast<S>(xq[B].w); \
+    const float w0 = quad_bcast<S>(wq[B].x), w1 = quad_bcast<S>(wq[B].y), w2 = quad_bcast<S>(wq[B].z), w3 = quad_bcast<S>(wq[B].w); \
+    const float xs = c == 0 ? x0 : c == 1 ? x1 : c == 2 ? x2 : x3;                                                            \
+    const float wv = c == 0 ? w0 : c == 1 ? w1 : c == 2 ? w2 : w3;                                                            \
+    const float pr = xs * wv; /* this file is compiled -ffp-contract=off: product and sum round separately */                \
+    acc = acc + pr;           /* (dnn.cc:233-238) */                                                                          \
+  }
+      FDNN_FIX_STEP(0, 0) FDNN_FIX_STEP(0, 1) FDNN_FIX_STEP(0, 2) FDNN_FIX_STEP(0, 3)
+      FDNN_FIX_STEP(1, 0) FDNN_FIX_STEP(1, 1) FDNN_FIX_STEP(1, 2) FDNN_FIX_STEP(1, 3)
+      FDNN_FIX_STEP(2, 0) FDNN_FIX_STEP(2, 1) FDNN_FIX_STEP(2, 2) FDNN_FIX_STEP(2, 3)
+#undef FDNN_FIX_STEP
+    }
+    const float c0 = quad_bcast<0>(acc), c1 = quad_bcast<1>(acc), c2 = quad_bcast<2>(acc), c3 = quad_bcast<3>(acc);
+    if (live && c == 0) {
+      const float lin = ((c0 + c1) + (c2 + c3)) + p.bias[node];  // horizontalSum (dnn.cc:168-172), AddBias
+      if (p.tap_lin) p.tap_lin[static_cast<size_t>(f) * p.H + node] = lin;
+      p.act_out[static_cast<size_t>(f) * p.act_ld + node] = static_cast<int8_t>(p.lut[lut_index(lin)]);
+      ++done;
+    }
+  }
+  (void)done;
+  __syncthreads();  // every thread has read the count and its entries
+  if (tid == 0) {
+    p.scr_count[tile_id] = 0;  // ready for the next launch
+    // ONE atomic per tile (one per recomputed output -- 80 000 on one address -- cost more than the recomputation)
+    if (p.scr_stats) atomicAdd(p.scr_stats + 1, static_cast<unsigned long long>(all ? TF * TN : count));
+  }
 }
 
 template <int BK, int WFR>
@@ -651,6 +878,25 @@ void launch_mfma(const L0Params &p, hipStream_t s) {
   hipLaunchKernelGGL(p.tap_lin ? k_tap : k_prod, grid, dim3(Cfg::THREADS), Cfg::LDS, s, p);
 }
 
+// Canonical numerics through the screened path: frame norms, fused chains + screening, exact recomputation of the flagged.
+void launch_screened(const L0Params &p, hipStream_t s) {
+  using Cfg = L0MfmaCfg<32, 4>;
+  static_assert(Cfg::TF == 128 && Cfg::TN == 128, "l0_fix_kernel assumes 128 x 128 tiles");
+  auto k_scr = l0_mfma_kernel<32, 4, false, true>;
+  static std::atomic<unsigned long long> attr_set{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long dev_bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_scr), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    attr_set.fetch_or(dev_bit, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(l0_xnorm_kernel, dim3((p.n + 3) / 4), dim3(256), 0, s, p.x, p.shift, p.scale, p.xnorm, p.n, p.D);
+  const int node_tiles = (p.H + 127) / 128, frame_tiles = (p.n_rows + 127) / 128;
+  hipLaunchKernelGGL(k_scr, dim3(l0_grid(node_tiles, frame_tiles)), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+  hipLaunchKernelGGL(l0_fix_kernel, dim3(node_tiles * frame_tiles), dim3(256), 2 * sizeof(float) * p.D, s, p);
+}
+
 }  // namespace
 
 void launch_l0(const L0Params &p, hipStream_t s) {
@@ -659,6 +905,13 @@ void launch_l0(const L0Params &p, hipStream_t s) {
     // 32-float chunks, 4 x 2 waves (128 x 128 tile).  Measured alternatives at 10 000 frames:
     // 16-float chunks 0.221 ms, 64-float 0.205, 256-thread workgroups (two per CU) 0.205.
     launch_mfma<32, 4>(p, s);
+    return;
+  }
+  // Large batches without taps: the screened path (fused chains on the matrix pipe + exact recomputation of the few
+  // outputs the fusion could change): 0.21 ms against 0.33 ms for the all-VALU chain kernel at 10 000 frames.
+  static const bool no_screen = std::getenv("FDNN_L0_NO_SCREEN") != nullptr;
+  if (!p.fma && !no_screen && p.kernel == 0 && !p.tap_lin && p.xnorm && p.wnorm && p.scr_count && p.scr_list && p.n >= 2048) {
+    launch_screened(p, s);
     return;
   }
   static const bool classic = std::getenv("FDNN_L0_CLASSIC") != nullptr;

@@ -9,9 +9,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -101,6 +103,24 @@ int build_l0_image(fdnn_model *m) {
   fdnn::launch_l0_weight_image(reinterpret_cast<const float *>(m->d_blob + h.off_w0), m->d_w0t, h.hidden, h.in_dim, m->l0_j_pad,
                                m->l0_h_ld, nullptr);
   HIP_TRY(hipGetLastError());
+  // ||w_n||_2 per layer-0 node, in double, rounded up to float: with the frame norms it bounds sum_k |x_k w_k| of every
+  // output (Cauchy-Schwarz) for the screened path (fdnn_l0.hip)
+  {
+    const float *w0 = m->hm.w0();
+    std::vector<float> wn(size_t(h.hidden));
+    for (int i = 0; i < h.hidden; ++i) {
+      double acc = 0.0;
+      for (int k = 0; k < h.in_dim; ++k) acc += double(w0[size_t(i) * h.in_dim + k]) * double(w0[size_t(i) * h.in_dim + k]);
+      const double up = std::sqrt(acc) * (1.0 + 1e-6);
+      float f = float(up);
+      if (double(f) < up) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+      wn[size_t(i)] = f;  // inf / NaN weights stay inf / NaN: every output of that node is then recomputed exactly
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_w0norm), sizeof(float) * wn.size()));
+    HIP_TRY(hipMemcpy(m->d_w0norm, wn.data(), sizeof(float) * wn.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_l0_stats), 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(m->d_l0_stats, 0, 2 * sizeof(unsigned long long)));
+  }
   HIP_TRY(hipDeviceSynchronize());
   return FDNN_OK;
 }
@@ -112,6 +132,9 @@ void destroy_ctx(fdnn_ctx *c) {
   hipFree(c->d_x);
   hipFree(c->d_xt);
   hipFree(c->d_l0park);
+  hipFree(c->d_xnorm);
+  hipFree(c->d_scr_count);
+  hipFree(c->d_scr_list);
   hipFree(c->d_act[0]);
   hipFree(c->d_act[1]);
   hipFree(c->d_out);
@@ -148,6 +171,13 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
   alloc(reinterpret_cast<void **>(&c->d_x), sizeof(float) * np * h.in_dim);
   c->xt_ld = round_up(c->cap, 128);
   alloc(reinterpret_cast<void **>(&c->d_xt), sizeof(float) * 4 * size_t(m->l0_j_pad) * c->xt_ld);
+  {  // screened layer-0 path: frame norms + the per-tile lists of outputs to recompute exactly
+    const size_t tiles = size_t(c->xt_ld / 128) * size_t((h.hidden + 127) / 128);
+    alloc(reinterpret_cast<void **>(&c->d_xnorm), sizeof(float) * size_t(c->xt_ld));
+    alloc(reinterpret_cast<void **>(&c->d_scr_count), sizeof(uint32_t) * tiles);
+    alloc(reinterpret_cast<void **>(&c->d_scr_list), sizeof(uint16_t) * tiles * fdnn::kL0ScreenCap);
+    if (e == hipSuccess) e = hipMemset(c->d_scr_count, 0, sizeof(uint32_t) * tiles);
+  }
   if (fdnn::l0_chain_node_tile() == 128)  // the 64-node tile keeps its partial sums in registers
     alloc(reinterpret_cast<void **>(&c->d_l0park), sizeof(float) * size_t(c->xt_ld) * m->l0_h_ld);
   alloc(reinterpret_cast<void **>(&c->d_act[0]), npt * c->act_ld);
@@ -239,9 +269,8 @@ fdnn::QGemmParams prepare_qlayer(fdnn_ctx *c, const QLayerDesc &d, const int8_t 
   return g;
 }
 
-// CalculateUntilLastHiddenLayer (dnn.cc:402-424): layer 0, then every int8
-// hidden layer, layer-major over the whole frame batch.
-int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
+// Layer 0 of the context's n frames into d_act[0] (shift/scale, fp32 affine, bias, table).
+void run_layer0(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
   fdnn_model *m = c->m;
   const BlobHeader &h = m->hm.hdr;
   const uint8_t *B = m->d_blob;
@@ -260,10 +289,15 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
   l0.D = h.in_dim;
   l0.H = h.hidden;
   l0.fma = m->l0_fma;
-  l0.kernel = m->l0_kernel;
+  l0.kernel = (c->l0_chain_only && m->l0_kernel == 0) ? 1 : m->l0_kernel;
   l0.xt = c->d_xt;
   l0.wt = m->d_w0t;
   l0.park = c->d_l0park;
+  l0.xnorm = c->d_xnorm;
+  l0.wnorm = m->d_w0norm;
+  l0.scr_count = c->d_scr_count;
+  l0.scr_list = c->d_scr_list;
+  l0.scr_stats = m->d_l0_stats;
   l0.j_pad = m->l0_j_pad;
   l0.jc = m->l0_jc;
   l0.n_ld = c->xt_ld;
@@ -272,6 +306,14 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
     ProfScope ps(m, s, FDNN_PROF_L0);
     fdnn::launch_l0(l0, s);
   }
+}
+
+// CalculateUntilLastHiddenLayer (dnn.cc:402-424): layer 0, then every int8
+// hidden layer, layer-major over the whole frame batch.
+int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
+  fdnn_model *m = c->m;
+  const BlobHeader &h = m->hm.hdr;
+  run_layer0(c, d_x, s, taps);
   int cur = 0;
   if (taps && taps->u8_acts) snapshot_acts(c, cur, taps->u8_acts, s);
   for (int qi = 0; qi < h.n_q - 1; ++qi) {
@@ -506,6 +548,8 @@ int fdnn_model_load_on(const char *path, float cutoff, int device, fdnn_model **
   if (rc) {
     if (m->d_blob) hipFree(m->d_blob);
     if (m->d_w0t) hipFree(m->d_w0t);
+    if (m->d_w0norm) hipFree(m->d_w0norm);
+    if (m->d_l0_stats) hipFree(m->d_l0_stats);
     delete m;
     return rc;
   }
@@ -584,6 +628,8 @@ void fdnn_model_free(fdnn_model *m) {
     DeviceGuard g(m->device);
     hipFree(m->d_blob);
     hipFree(m->d_w0t);
+    hipFree(m->d_w0norm);
+    hipFree(m->d_l0_stats);
   }
   delete m;
 }
@@ -853,6 +899,33 @@ int fdnn_debug_forward_taps(fdnn_model *m, const float *x, int n, const int8_t *
   return FDNN_OK;
 }
 
+int fdnn_debug_layer0(fdnn_model *m, const float *x, int n, uint8_t *u8_out, unsigned long long *recomputed) {
+  if (!m || !x || !u8_out || n <= 0) return fail(FDNN_E_ARG, "bad argument");
+  DeviceGuard g(m->device);
+  const BlobHeader &h = m->hm.hdr;
+  fdnn_ctx *c = nullptr;
+  int rc = make_ctx(m, n, &c);
+  if (rc) return rc;
+  unsigned long long before[2] = {0, 0}, after[2] = {0, 0};
+  hipError_t e = hipMemcpy(before, m->d_l0_stats, sizeof(before), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x, sizeof(float) * size_t(n) * h.in_dim, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    run_layer0(c, c->d_x, c->stream, nullptr);  // the PRODUCTION instance (no taps): screened path for large batches
+    e = hipGetLastError();
+  }
+  const size_t act_ld = size_t(c->act_ld);
+  std::vector<int8_t> tmp(size_t(n) * act_ld);
+  if (e == hipSuccess) e = hipMemcpyAsync(tmp.data(), c->d_act[0], tmp.size(), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(after, m->d_l0_stats, sizeof(after), hipMemcpyDeviceToHost);
+  fdnn_ctx_free(c);
+  if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("layer 0: ") + hipGetErrorString(e));
+  for (int f = 0; f < n; ++f)
+    for (int i = 0; i < h.hidden; ++i) u8_out[size_t(f) * h.hidden + i] = uint8_t(tmp[size_t(f) * act_ld + i]) ^ 0x80;
+  if (recomputed) *recomputed = after[1] - before[1];
+  return FDNN_OK;
+}
+
 // ---------------------------------------------------------------- per-kernel timing
 int fdnn_profile_begin(fdnn_model *m) {
   if (!m) return fail(FDNN_E_ARG, "null model");
@@ -940,6 +1013,8 @@ int fdnn_model_import_blob(const void *d_src, size_t bytes, int device, fdnn_mod
   if (rc) {
     hipFree(m->d_blob);
     if (m->d_w0t) hipFree(m->d_w0t);
+    if (m->d_w0norm) hipFree(m->d_w0norm);
+    if (m->d_l0_stats) hipFree(m->d_l0_stats);
     delete m;
     return rc;
   }

@@ -133,6 +133,7 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
   c->n = n;
   c->last = -1;
   const bool small = n <= kSmallBatch;
+  c->l0_chain_only = !small;  // see fdnn_ctx: the overlapped scale pass needs room beside layer 0
   hipStream_t cs = small ? sl.stream : s->s_main;
   if (after) HIP_TRY(hipStreamWaitEvent(cs, after, 0));
   HIP_TRY(fdnn::ctx_enter(c, cs));

@@ -236,6 +236,12 @@ FDNN_API int fdnn_debug_forward_taps(fdnn_model *m, const float *x, int n, const
  * tiles over chain-major images), 2 = always the 64 x 64-tile kernel. */
 FDNN_API int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind);
 
+/* Layer 0 alone through the PRODUCTION kernels (no taps): u8_out [n][hidden_dim].  Large batches take the
+ * screened path (fused chains on the fp32 matrix pipe, a rigorous bound on |fused - unfused|, exact unfused
+ * recomputation of the outputs whose table index the difference could change); *recomputed (may be NULL)
+ * receives how many outputs of this call were recomputed.  Tests compare u8_out with the oracle bit for bit. */
+FDNN_API int fdnn_debug_layer0(fdnn_model *m, const float *x, int n, uint8_t *u8_out, unsigned long long *recomputed);
+
 /* ------------------------------------------------------------------ per-kernel timing (bench / profiling only)
  * Between begin and end every kernel launch of this model is bracketed by HIP
  * events recorded on the stream it is launched on; end() synchronizes them and

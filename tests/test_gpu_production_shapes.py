@@ -231,3 +231,29 @@ def test_layer0_128_node_tile_still_bit_exact():
                         "input_widths or tiny_golden or blob_export or ragged_batch"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+@pytest.mark.parametrize("seed,scale", [(3, 1.0), (4, 4.0)])
+def test_screened_layer0_is_bit_exact(net_model_path, tmp_models, seed, scale):
+    """Large batches compute layer 0 with FUSED chains on the fp32 matrix pipe and recompute, with the
+    exact unfused chains (dnn.cc:219-247), only the outputs whose table index the fusion could change
+    (fdnn_l0.hip, "screened").  Every one of 4096 x 2048 layer-0 activations of the production kernels
+    against the oracle's canonical layer 0, bit for bit -- also with inputs four times larger (more
+    outputs in the sigmoid's tails, wider error bounds)."""
+    n = 4096
+    x = (F.synth_features(n, 432, seed=seed) * np.float32(scale)).astype(np.float32)
+    want, wt = Oracle(net_model_path).calculate(x[:8], taps=True)   # cheap sanity that the oracle is up
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    got, recomputed = dnn.layer0(x)
+    assert 0 < recomputed < 0.25 * n * 2048, recomputed   # the screened path ran, and screening is selective
+    # the oracle's canonical layer 0 for all frames: hidden layers are not needed, so score in slices
+    orc = Oracle(net_model_path)
+    for lo in range(0, n, 512):
+        _, t = orc.calculate(x[lo:lo + 512], taps=True)
+        bad = np.argwhere(got[lo:lo + 512] != t["u8_acts"][0])
+        assert bad.size == 0, (lo, bad[:5].tolist())
+    # the all-VALU chain kernel gives the same bytes (kind 1 forces it)
+    dnn.setInputLayerKernel(1)
+    chain, rec2 = dnn.layer0(x)
+    assert rec2 == 0 and np.array_equal(chain, got)
+    dnn.delete()
