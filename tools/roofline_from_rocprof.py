@@ -43,6 +43,18 @@ for r in rows:
         ent = dict(kernel="l0_chain_kernel (fp32, multiply and add rounded separately)", bound="valu",
                    achieved=round(2.0 * D * H * n / (avg_us * 1e-6) / 1e12, 1), peak=78.65, unit="TFLOP/s",
                    algorithmic_bytes_per_launch=4 * (D * n + D * H) + H * n, traffic=traffic("l0_chain_kernel"))
+    elif "l0_mfma_kernel" in nm:
+        ent = dict(kernel="l0_mfma_kernel (fp32 MFMA chains" + (", screened: canonical numerics)" if "true>" in nm.replace(" ", "") else ")"), bound="mfma",
+                   achieved=round(2.0 * D * H * n / (avg_us * 1e-6) / 1e12, 1), peak=157.3, unit="TFLOP/s",
+                   algorithmic_bytes_per_launch=4 * (D * n + D * H) + H * n, traffic=traffic("l0_mfma_kernel"))
+    elif "l0_fix_kernel" in nm:
+        ent = dict(kernel="l0_fix_kernel (exact unfused chains of the screened outputs, ~0.4 %)", bound="hbm",
+                   achieved=round(0.004 * n * H * 2 * 4 * D / (avg_us * 1e-6) / 1e9, 1), peak=8000.0, unit="GB/s",
+                   algorithmic_bytes_per_launch=int(0.004 * n * H * 2 * 4 * D), traffic=traffic("l0_fix_kernel"))
+    elif "l0_xnorm_kernel" in nm:
+        ent = dict(kernel="l0_xnorm_kernel (frame norms for the screened path's bound)", bound="hbm",
+                   achieved=round(4.0 * D * n / (avg_us * 1e-6) / 1e9, 1), peak=8000.0, unit="GB/s",
+                   algorithmic_bytes_per_launch=4 * D * n, traffic=traffic("l0_xnorm_kernel"))
     elif "l0_image_kernel" in nm:
         ent = dict(kernel="l0_image_kernel (shift/scale + chain-major transpose of the frames)", bound="hbm",
                    achieved=round(2.0 * 4 * D * n / (avg_us * 1e-6) / 1e9, 1), peak=8000.0, unit="GB/s",
