@@ -332,6 +332,33 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
       const int node = static_cast<int>(fix_raw >> 32) - (m0 + 64 * wm);  // 0..63
       const int kl = static_cast<int>(fix_raw & 0xffff) - kt * BK;          // even, 0..BK-2
       const int w0 = static_cast<int8_t>(fix_raw >> 16), w1 = static_cast<int8_t>(fix_raw >> 24);
+      // Screen first.  A pair that CAN saturate almost never does (both activations must be
+      // close to 255: 0.2 % of the (pair, frame) combinations of the Gaussian bench net, under
+      // 1 % of the pairs for any of a wave's 160 frames), so the common case only has to prove
+      // "no frame of this wave saturates": one frame per lane (not per half-wave as the
+      // accumulator layout has it), the pair as one 16-bit LDS read, the pair product as one
+      // v_dot4c_i32_i8 on the staged s8 bytes (a = s8 + 128, so p = dot + 128*(w0+w1)), one
+      // range test.  Only when some lane fires does the wave run the exact correction below.
+      {
+        const int wpk = (w0 & 0xff) | ((w1 & 0xff) << 8);
+        const int pbase = 128 * (w0 + w1) + 32768;
+        bool fire = false;
+#pragma unroll
+        for (int j = 0; j < (NF + 1) / 2; ++j) {
+          const int row = arow0 + 64 * j + lane;
+          const int v = *reinterpret_cast<const uint16_t *>(at + row * BK + (((kl >> 4) ^ swz<BK>(row)) << 4) + (kl & 15));
+          const int ps = __builtin_amdgcn_sdot4(v, wpk, pbase, false);  // p + 32768
+          const bool live = 64 * j + 64 <= 32 * NF || lane < 32 * NF - 64 * j;
+          fire |= live && static_cast<unsigned>(ps) > 65535u;
+        }
+        if (__ballot(fire) == 0ull) {
+          ++fix_e;
+          fix_raw = fix_raw_nxt;
+          fix_k_next = fix_e < fix_end ? static_cast<int>(fix_raw & 0xffff) : INT_MAX;
+          if (fix_e + 1 < fix_end) fix_raw_nxt = ent_c[fix_e + 1];
+          continue;
+        }
+      }
       const int rr = node & 31;
       const int idx = (node >> 5) * 16 + (rr & 3) + 4 * (rr >> 3);  // mi*16 + reg
       const bool mine = (lane >> 5) == ((rr >> 2) & 1);
