@@ -907,24 +907,28 @@ void launch_l0(const L0Params &p, hipStream_t s) {
     launch_mfma<32, 4>(p, s);
     return;
   }
-  // Large batches without taps: the screened path (fused chains on the matrix pipe + exact recomputation of the few
-  // outputs the fusion could change): 0.21 ms against 0.33 ms for the all-VALU chain kernel at 10 000 frames.
+  // Three bit-identical candidates, chosen by modelled time (432 -> 2048 layer, tools/l0_kind_sweep.py; all three
+  // come in rounds of 256 tiles, one per CU, and a round costs the same full or not):
+  //   screened   fused chains on the matrix pipe + exact recomputation of the few outputs the fusion could change
+  //              (128 x 128 tiles): 74 / 122 / 174 / 234 / 285 us for 1..5 rounds; large batches without taps only
+  //   chain      all-VALU chain kernel (128 frames x 64 nodes): 57 / 82 / 110 / 142 / 171 / 203 us for 1..6 rounds
+  //   tile64     64 x 64 tiles, 4 x 4 outputs per thread: 45 us up to 512 frames, then 20 us + 35.5 ns per frame
+  // e.g. 2560 frames: 120 screened, 109 chain; 3000: 110 chain, 125 the others; 6000: 174 screened, 204 chain.
   static const bool no_screen = std::getenv("FDNN_L0_NO_SCREEN") != nullptr;
-  if (!p.fma && !no_screen && p.kernel == 0 && !p.tap_lin && p.xnorm && p.wnorm && p.scr_count && p.scr_list && p.n >= 2048) {
+  static const bool classic = std::getenv("FDNN_L0_CLASSIC") != nullptr;
+  const double work = static_cast<double>(p.D) / 432.0;
+  const long ft128 = (p.n_rows + 127) / 128;
+  const double screened_us = 18.0 + 54.0 * work * static_cast<double>((ft128 * ((p.H + 127) / 128) + 255) / 256);
+  const double chain_us = 27.0 + 30.0 * work * static_cast<double>((ft128 * (p.h_ld / l0_chain_node_tile()) + 255) / 256);
+  const double tile64_us = p.n_rows <= 512 ? 45.0 * work : 20.0 + 0.0355 * work * (p.H / 2048.0) * p.n_rows;
+  const bool can_screen = !p.fma && !no_screen && p.kernel == 0 && !p.tap_lin && p.xnorm && p.wnorm && p.scr_count && p.scr_list && p.n >= 2048;
+  const bool can_chain = !p.fma && p.xt && p.wt && p.kernel != 2 && !(classic && p.kernel == 0);
+  if (can_screen && screened_us < (can_chain ? chain_us : tile64_us) && screened_us < tile64_us) {
     launch_screened(p, s);
     return;
   }
-  static const bool classic = std::getenv("FDNN_L0_CLASSIC") != nullptr;
-  // The chain kernel's 128 x 128 tiles pay off once they fill the chip: a CU turns one over in
-  // ~67 us (432 inputs) and tiles come in rounds of 256, while the 64 x 64 tiles of the classic
-  // kernel scale linearly (37.5 ns per frame of a 432 -> 2048 layer + 20 us).  Measured
-  // crossover for that layer: between 3000 and 4000 frames (tools/l0_sweep.sh).
-  const double work = static_cast<double>(p.D) / 432.0;
-  const long tiles = static_cast<long>((p.n_rows + 127) / 128) * (p.h_ld / 128);
-  const double chain_ms = 0.015 + 0.067 * work * static_cast<double>((tiles + 255) / 256);
-  const double classic_ms = 0.020 + 37.5e-6 * work * (p.H / 2048.0) * p.n_rows;
-  const bool chain = p.kernel == 1 || (p.kernel == 0 && !classic && chain_ms < classic_ms);
-  if (!p.fma && chain && p.xt && p.wt) {
+  const bool chain = can_chain && (p.kernel == 1 || chain_us < tile64_us);
+  if (chain) {
     if (p.jc == 12)
       launch_chain<12>(p, s);
     else

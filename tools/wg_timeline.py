@@ -22,8 +22,12 @@ print("records", len(rows))
 # group into launches: sort by start time, a launch = 256 consecutive blocks
 rows.sort(key=lambda t: t[1])
 launches = [rows[i:i + 256] for i in range(0, len(rows) - 255, 256)]
+prev_end = None
 for L in launches[-12:]:
     t0 = min(a for _, a, _ in L); t1 = max(b for _, _, b in L)
+    if prev_end is not None:
+        print(f"   first instruction {(t0 - prev_end) * 0.01:5.1f} us after the previous launch's last s_endpgm")
+    prev_end = t1
     starts = sorted(a - t0 for _, a, _ in L); ends = sorted(t1 - b for _, _, b in L); dur = sorted(b - a for _, a, b in L)
     tick = 0.01  # us per s_memrealtime tick (100 MHz)
     byx = collections.defaultdict(list)
