@@ -125,9 +125,29 @@ def cpu_baseline(model_path: str, frames: int = 100) -> dict:
     utts = 2
     wall, per = run(usable, utts)
     many = usable * utts * frames / wall
+    # the reference itself (oracle/_ref, compiled from the reference's own sources where they were available), one thread,
+    # same utterance: times the real code beside the port and checks that the two agree on this sample
+    ref_one = ref_diff = None
+    try:
+        from oracle.oracle import RefLib
+
+        ref = RefLib().load(model_path)
+        y_ref = ref.calculate(x, 8)  # warm-up
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            y_ref = ref.calculate(x, 8)
+            ts.append(time.perf_counter() - t0)
+        ref_one = frames / float(np.median(ts))
+        ref_diff = float(np.abs(y_ref - orc.calculate(x, 8)).max())
+        ref.close()
+    except (OSError, FileNotFoundError):
+        pass
     return {
         "value": round(many, 1), "unit": "frames/s", "cores": usable, "kind": "port",
         "value_1thread": round(one, 1),
+        "reference_value_1thread": None if ref_one is None else round(ref_one, 1),
+        "reference_vs_port_max_abs_diff": ref_diff,
         "scaling_vs_1thread": round(many / one, 2),
         "slowest_thread_s": round(max(per), 3), "fastest_thread_s": round(min(per), 3),
         "host": host,
