@@ -47,16 +47,20 @@
 #ifndef FDNN_GEMM_DEBUG
 #define FDNN_GEMM_DEBUG 0
 #endif
+#ifndef FDNN_SMALL_STAGES
+#define FDNN_SMALL_STAGES 3  // ring depth of the 256-node x 32-frame tile (4: no change measured)
+#endif
 
 
 namespace fdnn {
 namespace {
 
-constexpr int G_BM = 256;
-
-template <int NF, int WN, int BK, int STAGES>
+// WM waves along the nodes (64 each): 4 = the 256-node tile of every large shape; 2 / 1 = the 128- / 64-node tiles of
+// the smallest batches, where one workgroup's operand stream is what a launch waits for (see launch_qgemm).
+template <int NF, int WN, int BK, int STAGES, int WM = 4>
 struct GemmCfg {
-  static constexpr int NW = 4 * WN;                  // waves
+  static constexpr int G_BM = 64 * WM;               // nodes per workgroup tile
+  static constexpr int NW = WM * WN;                 // waves
   static constexpr int THREADS = 64 * NW;
   static constexpr int FT = 32 * NF * WN;            // frames per workgroup tile
   static constexpr int RPI = 1024 / BK;              // rows per 1-KiB wave instruction
@@ -98,11 +102,12 @@ __device__ __forceinline__ v4i read_frag(const char *tile, int row, int chunk) {
 // no taps; the mask only selects z = 0 for inactive nodes (with ANYW for widths % 4 != 0).
 // ANYW (with PLAIN): the dense call for every other output width (pdf counts are arbitrary):
 // per-element range test, 4-byte-aligned dwordx4 stores, scalar stores for a row's last group.
-template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool TAP, bool FAST, bool PLAIN = false, bool MASKED = false, bool ANYW = false>
-__global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
+template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool TAP, bool FAST, bool PLAIN = false, bool MASKED = false, bool ANYW = false,
+          int WM = 4>
+__global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (buffer-resource builtins are device-only)
-  using Cfg = GemmCfg<NF, WN, BK, STAGES>;
-  constexpr int FT = Cfg::FT, NW = Cfg::NW;
+  using Cfg = GemmCfg<NF, WN, BK, STAGES, WM>;
+  constexpr int FT = Cfg::FT, NW = Cfg::NW, G_BM = Cfg::G_BM;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #if FDNN_GEMM_DEBUG & 64
   long long ts[6], ts_fix = 0;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
+  const int wm = wave % WM, wn = wave / WM;
 
   // Workgroup b runs on XCD b%8 (strictly so for the first round of a launch; later rounds the
   // dispatcher skips a full XCD now and then -- a locality hint, nothing may depend on it).
@@ -147,6 +152,9 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
   // scalar offset for slab + k-step.  Flat per-load 64-bit addresses cost two VGPRs per
   // load; at 256 VGPRs the compiler spilled them and each scratch reload drained the
   // whole LDS-DMA queue (s_waitcnt vmcnt(0)) inside the k-loop.
+  // (a one-wave workgroup takes EVERY slab: the parity then alternates with the slab index, which is a compile-time
+  // constant of the unrolled load -- the odd slabs flip bit 6 of the offset, see stage_load)
+  static_assert(NW % 2 == 0 || NW == 1, "slab parity per wave needs an even wave count (or one wave)");
   const int srow = lane / Cfg::LPR;
   const int schunk = ((lane % Cfg::LPR) ^ swz<BK>(wave * Cfg::RPI + srow)) << 4;
   const int voff_w = srow * p.ldw + schunk;
@@ -163,14 +171,17 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
   auto stage_load = [&](int kt, int buf, int i) {
     char *base = smem + buf * Cfg::STAGE;
     const int koff = kt * BK;
+    // swz<128>(8 * slab + srow) = (4 * slab + (srow >> 1)) & 7: an odd slab flips chunk bit 2 = offset bit 6 (the row
+    // strides are multiples of 128 bytes, so the flip stays inside the chunk field)
+    const int odd = (NW == 1 && BK == 128) ? 64 : 0;
     if (i < NLD_W) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, FDNN_LDS_PTR(base + (i * NW + wave) * 1024), 16, voff_w,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, FDNN_LDS_PTR(base + (i * NW + wave) * 1024), 16, (i & 1) ? voff_w ^ odd : voff_w,
                                                (i * NW + wave) * Cfg::RPI * p.ldw + koff, 0, 0);
     } else {
       const int s = i - NLD_W;
       if (Cfg::A_SLABS % NW == 0 || s * NW + wave < Cfg::A_SLABS)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, FDNN_LDS_PTR(base + Cfg::W_BYTES + (s * NW + wave) * 1024), 16,
-                                                 voff_a, (s * NW + wave) * Cfg::RPI * p.lda + koff, 0, 0);
+                                                 (s & 1) ? voff_a ^ odd : voff_a, (s * NW + wave) * Cfg::RPI * p.lda + koff, 0, 0);
     }
   };
   auto stage = [&](int kt, int buf) {
@@ -181,7 +192,10 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
   // The epilogue's sigmoid table and biases ride the same LDS-DMA queue, ahead of the ring
   // (older loads complete first, so every wait that covers stage 0 covers them too).
   char *aux = smem + Cfg::AUX_OFF;
-  if (!OUTPUT && wave < 3) {
+  // four 1-KiB pieces (three of table, one of biases) over however many waves there are
+#pragma unroll
+  for (int piece = 0; piece < 3; ++piece)
+  if (!OUTPUT && piece % NW == wave) {
     // The range of a 16-byte LDS-DMA access is checked as a whole: with num_records = the table
     // size, the lane holding the table's last three (FAST) / last one (exact) entries read zeros --
     // u8 128 instead of 255 for every activation with lin >= 6.395 (found by
@@ -190,9 +204,9 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     const int bytes = ((FAST ? kLut2Size : kLutExt) + 15) & ~15;
     const __amdgpu_buffer_rsrc_t rsrc_lut =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(FAST ? p.lut2 : p.lut), 0, bytes, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lut, FDNN_LDS_PTR(aux + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lut, FDNN_LDS_PTR(aux + piece * 1024), 16, lane * 16, piece * 1024, 0, 0);
   }
-  if (wave == 3) {
+  if (wave == 3 % NW) {
     const __amdgpu_buffer_rsrc_t rsrc_bias =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.bias + m0), 0, G_BM * 4, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_bias, FDNN_LDS_PTR(aux + 3072), 16, lane * 16, 0, 0, 0);
@@ -660,8 +674,8 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
   if (!OUTPUT) {
     // the s8 activation tile: FT rows x 256 bytes, written as 16 bytes per lane
     __syncthreads();
-    for (int item = tid; item < FT * 16; item += Cfg::THREADS) {
-      const int row = item >> 4, ch = item & 15;
+    for (int item = tid; item < FT * (G_BM / 16); item += Cfg::THREADS) {
+      const int row = item / (G_BM / 16), ch = item % (G_BM / 16);
       const uint4 v = *reinterpret_cast<const uint4 *>(tile_s + row * kTS + ch * 16);
 #if FDNN_GEMM_DEBUG & 16
       if (v.x == 0x12345678u && row == -7)
@@ -682,7 +696,7 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
     for (int ni = 0; ni < NF; ++ni) {
       const float tot = psum[ni] + __shfl_xor(psum[ni], 32);
       const int f = fw0 + 32 * ni + frow;
-      if (half == 0) p.partial[static_cast<size_t>(mt * 4 + wm) * p.partial_ld + f] = tot;
+      if (half == 0) p.partial[static_cast<size_t>(mt * WM + wm) * p.partial_ld + f] = tot;
     }
   }
 #if FDNN_GEMM_DEBUG & 64
@@ -702,17 +716,17 @@ __global__ __launch_bounds__(256 * WN, 2) void qgemm_kernel(QGemmParams p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool FAST = true>
+template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool FAST = true, int WM = 4>
 void launch_cfg(const QGemmParams &p, hipStream_t s) {
-  using Cfg = GemmCfg<NF, WN, BK, STAGES>;
-  const int MT = p.rows_pad / G_BM, NT = p.n_pad / Cfg::FT;
+  using Cfg = GemmCfg<NF, WN, BK, STAGES, WM>;
+  const int MT = p.rows_pad / Cfg::G_BM, NT = p.n_pad / Cfg::FT;
   const int blocks = 8 * MT * ((NT + 7) / 8);
-  auto k_prod = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST>;
-  auto k_tap = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, true, FAST>;
-  auto k_plain = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT>;  // hidden layers: same as k_prod
-  auto k_masked = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT>;
-  auto k_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, false, OUTPUT>;
-  auto k_masked_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT, OUTPUT>;
+  auto k_prod = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, false, false, false, WM>;
+  auto k_tap = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, true, FAST, false, false, false, WM>;
+  auto k_plain = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, false, false, WM>;  // hidden layers: same as k_prod
+  auto k_masked = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT, false, WM>;
+  auto k_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, false, OUTPUT, WM>;
+  auto k_masked_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT, OUTPUT, WM>;
   // the attribute is per device: a process may hold models on several GPUs
   static std::atomic<unsigned long long> attr_set{0};
   int dev = 0;
@@ -757,12 +771,27 @@ void launch_qgemm(const QGemmParams &p, hipStream_t s) {
     // 2048 x 2048 layer.  What is left at this size is mostly the launch itself: a 128-node tile
     // (half the operand traffic per workgroup) and whole-step fragment prefetch, both tried, left
     // the 16.6 us untouched.
-    case 32:
-      if (small_bk == 128)
-        launch_cfg<1, 1, 128, 3, OUTPUT>(p, s);
+    // ... and while the 32-frame tiles leave CUs idle or nearly so, a launch waits for ONE workgroup's operand stream: 288
+    // rows x 2 KiB at the ~70 GB/s one CU's LDS-DMA path moves = 8 of the 17 us of a 2048 x 2048 layer, whatever the frame
+    // count.  64-node tiles (one wave per workgroup) split the same weight rows over four times as many CUs: six hidden
+    // layers 101-110 -> 88-98 us from 8 to 700 frames (tools/batch_sweep.py; up to three workgroups per CU, beyond that
+    // the extra activation traffic loses).  Hidden layers only: the output layer's exp / transposition epilogue makes its
+    // narrow tiles slower (27 vs 21 us).
+    case 32: {
+      static const int force_wm = [] {
+        const char *e = std::getenv("FDNN_SMALL_WM");
+        return e ? std::atoi(e) : 0;
+      }();
+      const long wgs256 = static_cast<long>(p.rows_pad / 256) * (p.n_pad / 32);
+      const int wm = force_wm ? force_wm : (!OUTPUT && wgs256 * 4 <= 768) ? 1 : 4;
+      if (small_bk == 128 && wm == 1)
+        launch_cfg<1, 1, 128, 4, OUTPUT, true, 1>(p, s);
+      else if (small_bk == 128)
+        launch_cfg<1, 1, 128, FDNN_SMALL_STAGES, OUTPUT>(p, s);
       else
         launch_cfg<1, 1, 64, 6, OUTPUT>(p, s);
       break;
+    }
     case 64:
       if (small_bk == 128)
         launch_cfg<2, 1, 128, 3, OUTPUT>(p, s);
@@ -773,7 +802,7 @@ void launch_qgemm(const QGemmParams &p, hipStream_t s) {
     // a CU of its own anyway (small batches: one latency-bound k-loop per launch) a 6-stage
     // ring hides twice the load latency per step
     case 128:
-      if (static_cast<long>(p.rows_pad / G_BM) * (p.n_pad / 128) <= 256 && !p.tap_acc) {
+      if (static_cast<long>(p.rows_pad / 256) * (p.n_pad / 128) <= 256 && !p.tap_acc) {
         if (small_bk == 128)
           launch_cfg<4, 1, 128, 3, OUTPUT>(p, s);
         else
@@ -805,7 +834,7 @@ int qgemm_frame_tile(int rows_pad, int n) {
     return e ? std::atoi(e) : 0;
   }();
   if (forced == 32 || forced == 64 || forced == 128 || forced == 160 || forced == 256 || forced == 320) return forced;
-  const int mt = rows_pad / G_BM;
+  const int mt = rows_pad / 256;
   // Few frames: while every workgroup gets a CU of its own the launch is one k-loop deep and
   // latency bound, so the smallest tile that still fits in one round wins -- it has the shortest
   // k-step and puts the most CUs to work (2048 x 2048 layer, 1000 frames: 21 us with 32-frame

@@ -912,7 +912,8 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   //   screened   fused chains on the matrix pipe + exact recomputation of the few outputs the fusion could change
   //              (128 x 128 tiles): 74 / 122 / 174 / 234 / 285 us for 1..5 rounds; large batches without taps only
   //   chain      all-VALU chain kernel (128 frames x 64 nodes): 57 / 82 / 110 / 142 / 171 / 203 us for 1..6 rounds
-  //   tile64     64 x 64 tiles, 4 x 4 outputs per thread: 45 us up to 512 frames, then 20 us + 35.5 ns per frame
+  //   tile64     (16 | 32 | 64) x 64 tiles, 4 outputs x 4 chains per thread and frame: 19-23 us up to 400 frames, 33-49 us up to
+  //              1200, then 20 us + 35.5 ns per frame
   // e.g. 2560 frames: 120 screened, 109 chain; 3000: 110 chain, 125 the others; 6000: 174 screened, 204 chain.
   static const bool no_screen = std::getenv("FDNN_L0_NO_SCREEN") != nullptr;
   static const bool classic = std::getenv("FDNN_L0_CLASSIC") != nullptr;
@@ -920,7 +921,9 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   const long ft128 = (p.n_rows + 127) / 128;
   const double screened_us = 18.0 + 54.0 * work * static_cast<double>((ft128 * ((p.H + 127) / 128) + 255) / 256);
   const double chain_us = 27.0 + 30.0 * work * static_cast<double>((ft128 * (p.h_ld / l0_chain_node_tile()) + 255) / 256);
-  const double tile64_us = p.n_rows <= 512 ? 45.0 * work : 20.0 + 0.0355 * work * (p.H / 2048.0) * p.n_rows;
+  const double tile64_us = p.n_rows <= 320    ? 23.0 * work
+                           : p.n_rows <= 1200 ? (17.0 + 0.032 * p.n_rows) * work
+                                              : 20.0 + 0.0355 * work * (p.H / 2048.0) * p.n_rows;
   const bool can_screen = !p.fma && !no_screen && p.kernel == 0 && !p.tap_lin && p.xnorm && p.wnorm && p.scr_count && p.scr_list && p.n >= 2048;
   const bool can_chain = !p.fma && p.xt && p.wt && p.kernel != 2 && !(classic && p.kernel == 0);
   if (can_screen && screened_us < (can_chain ? chain_us : tile64_us) && screened_us < tile64_us) {
@@ -937,7 +940,19 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   }
   // 64 x 64 tile, 16-float chunks, 4 x 4 outputs per thread.  Measured alternatives: 32-float
   // chunks 0.448 ms, 8 x 4 outputs per thread 0.468 / 0.477 ms (occupancy 2) against 0.388.
-  launch_valu<4, 16>(p, s);
+  static const int t64_bk = [] {
+    const char *e = std::getenv("FDNN_L0_T64_BK");
+    return e ? std::atoi(e) : 0;
+  }();
+  // Few frames: a 64 x 64 tile is 30-40 us of dependent vector work for ONE workgroup however few of them there are, so
+  // small batches take 16- / 32-frame tiles (more, shorter workgroups).  Measured (tools/l0_kind_sweep.py), 8 / 100 / 256 /
+  // 512 / 1000 frames: 16 x 64 tiles 19 / 21 / 23 / 38 / 60 us, 32 x 64 27 / 30 / 30 / 33 / 49, 64 x 64 43 / 45 / 45 / 45 / 55.
+  if (t64_bk == 164 || (t64_bk == 0 && p.n_rows <= 320))
+    launch_valu<1, 64>(p, s);
+  else if (t64_bk == 232 || (t64_bk == 0 && p.n_rows <= 1200))
+    launch_valu<2, 32>(p, s);
+  else
+    launch_valu<4, 16>(p, s);
 }
 
 // Node tile of the chain kernel: 64 (8 frames x 4 nodes per thread, every partial sum in registers,
