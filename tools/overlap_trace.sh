@@ -27,7 +27,7 @@ rows = list(csv.DictReader(open(f)))
 ev = []
 for r in rows:
     nm = r["Kernel_Name"]
-    short = "norm" if "normalize" in nm else "l0img" if "l0_image" in nm else "l0" if "l0_chain" in nm else "out" if "qgemm" in nm and "true" in nm.split("qgemm_kernel<")[1].split(">")[0].replace(" ","").split(",")[4] else "hid" if "qgemm" in nm else None
+    short = "inv" if "softmax_inv" in nm else "norm" if "normalize" in nm else "l0img" if "l0_image" in nm else "l0" if "l0_chain" in nm else "l0mfma" if "l0_mfma" in nm else "l0fix" if "l0_fix" in nm else "xnorm" if "l0_xnorm" in nm else "out" if "qgemm" in nm and "true" in nm.split("qgemm_kernel<")[1].split(">")[0].replace(" ","").split(",")[4] else "hid" if "qgemm" in nm else None
     if short: ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short))
 ev.sort()
 ev = ev[len(ev) // 2:]   # steady state
