@@ -1,6 +1,6 @@
 """Randomised parity run against the CPU oracle (test infrastructure): random topologies (input
 width x4, hidden x16, any output width), weight scales from no saturating pairs to most pairs
-saturating, random batch sizes across every kernel-selection branch, random masks.
+saturating, both layer-0 flavours, random batch sizes across every kernel-selection branch, random masks.
 Checked per case: every layer's u8 activations and int32 accumulators through the tap kernels
 (bit-exact), the production kernels' last hidden layer (hiddenActivations, bit-exact), dense and
 lazy soft-max (<= 2e-6), and the dense result through the scoring loop (bit-identical to the call).
@@ -34,8 +34,12 @@ for case in range(cases):
     x = F.synth_features(n, in_dim, seed=seed + 1, pad_from=None) * np.float32(rng.choice([0.3, 1.0, 3.0]))
     masks = (rng.random((n, out)) < rng.choice([0.05, 0.4, 0.9])).astype(np.int8)
     tag = f"case {case}: topo {topo} n {n} w_std {w_std} seed {seed}"
+    fma = bool(rng.random() < 0.25)  # the reference as its own -march=native Makefile builds it: fused layer 0
+    tag += f" fma {fma}"
+    Oracle.set_l0_fma(fma)
     orc = Oracle(path)
     dnn = api.QuantizedDnn.loadFromFile(path)
+    dnn.setInputLayerFma(fma)
     want, wt = orc.calculate(x, taps=True)
     taps = dnn.forwardTaps(x)
     for k in ("u8_acts", "acc_hid", "acc_out"):
@@ -69,6 +73,7 @@ for case in range(cases):
     srv.close()
     dnn.delete()
     orc.close()
+    Oracle.set_l0_fma(False)
     worst = max(worst, err, lerr)
     if case % 10 == 9:
         print(f"{case + 1} cases, worst soft-max error {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
