@@ -4,7 +4,9 @@
 //   mode: percall  = fdnn_calculate per utterance (what the JNI calculate() does)
 //         server   = fdnn_server_submit + fdnn_server_wait (coalesced host submissions)
 //         batcher  = fdnn_calculate on a model with fdnn_model_enable_batcher
+//         fresh    = percall into a newly allocated, zero-filled result block per call (the reference shim's shape)
 // Prints one JSON line.  Build: see tools/serve_bench.sh.
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -49,7 +51,8 @@ int main(int argc, char **argv) {
     for (float &v : xs[size_t(t)]) v = nd(rng);
     outs[size_t(t)].assign(size_t(F) * O, 0.0f);  // resident, like a reused JVM float[]
   }
-  int failed = 0;
+  std::atomic<int> failed{0};
+  static thread_local float sink = 0.0f;
   auto body = [&](int t, int utts) {
     for (int u = 0; u < utts; ++u) {
       int rc;
@@ -57,6 +60,10 @@ int main(int argc, char **argv) {
         uint64_t ticket = 0;
         rc = fdnn_server_submit(srv, xs[size_t(t)].data(), F, nullptr, outs[size_t(t)].data(), &ticket);
         if (!rc) rc = fdnn_server_wait(srv, ticket);
+      } else if (mode == "fresh") {  // the reference shim's shape: a new zero-filled result block per call (jni_dnn.cc:49-57)
+        std::vector<float> fresh(size_t(F) * O);
+        rc = fdnn_calculate(m, xs[size_t(t)].data(), F, D, 10, fresh.data());
+        sink += fresh[size_t(u) % fresh.size()];
       } else {
         rc = fdnn_calculate(m, xs[size_t(t)].data(), F, D, 10, outs[size_t(t)].data());
       }
@@ -78,9 +85,9 @@ int main(int argc, char **argv) {
   if (srv) fdnn_server_stats(srv, &batches, &frames, &reqs, &coal);
   std::printf("{\"mode\": \"%s\", \"threads\": %d, \"frames_per_utt\": %d, \"utts\": %d, \"seconds\": %.4f, \"utts_per_s\": %.1f, "
               "\"frames_per_s\": %.1f, \"row0_sum\": %.6f, \"failed\": %d, \"batches\": %llu, \"requests\": %llu}\n",
-              mode.c_str(), T, F, T * U, sec, T * U / sec, double(T) * U * F / sec, sum, failed, (unsigned long long)batches,
+              mode.c_str(), T, F, T * U, sec, T * U / sec, double(T) * U * F / sec, sum, failed.load(), (unsigned long long)batches,
               (unsigned long long)reqs);
   if (srv) fdnn_server_free(srv);
   fdnn_model_free(m);
-  return failed ? 1 : 0;
+  return failed.load() ? 1 : 0;
 }
