@@ -9,6 +9,7 @@
 //     argument errors) with fdnn_last_error() instead of crashing / exit(3)
 //     (float_dnn.cc:171, :185-188).
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "../../include/fdnn.h"
@@ -33,13 +34,13 @@ using ReleaseByteArrayElementsFn = void (*)(JNIEnv *, jbyteArray, jbyte *, jint)
 using ReleaseFloatArrayElementsFn = void (*)(JNIEnv *, jfloatArray, jfloat *, jint);
 using SetFloatArrayRegionFn = void (*)(JNIEnv *, jfloatArray, jsize, jsize, const jfloat *);
 
-void throw_status(JNIEnv *env, int rc) {
+void throw_status(JNIEnv *env, int rc, const char *msg = nullptr) {
   const char *cls_name = rc == FDNN_E_ARG ? "java/lang/IllegalArgumentException" : "java/lang/RuntimeException";
   auto find = slot<FindClassFn>(env, FDNN_JNI_FindClass);
   auto thr = slot<ThrowNewFn>(env, FDNN_JNI_ThrowNew);
   if (!find || !thr) return;
   jclass cls = find(env, cls_name);
-  if (cls) thr(env, cls, fdnn_last_error());
+  if (cls) thr(env, cls, msg ? msg : fdnn_last_error());
 }
 
 // Native staging of a call's results: one block per calling thread, reused, so that its pages are resident.  A fresh
@@ -60,8 +61,8 @@ struct Scratch {
   float *get(size_t floats) {
     if (floats > cap) {
       release();
-      p = new float[floats];
-      cap = floats;
+      p = new (std::nothrow) float[floats];
+      cap = p ? floats : 0;
     }
     return p;
   }
@@ -105,11 +106,11 @@ jfloatArray Java_suskun_nn_QuantizedDnn_calculate(JNIEnv *env, jobject, jlong ha
   jfloat *elements = slot<GetFloatArrayElementsFn>(env, FDNN_JNI_GetFloatArrayElements)(env, flat, nullptr);
   const size_t len = static_cast<size_t>(n) * static_cast<size_t>(fdnn_model_output_dim(m));
   float *out = t_scratch.get(len);
-  int rc = fdnn_calculate(m, elements, n, dim, batch, out);
+  int rc = out ? fdnn_calculate(m, elements, n, dim, batch, out) : FDNN_E_NOMEM;
   slot<ReleaseFloatArrayElementsFn>(env, FDNN_JNI_ReleaseFloatArrayElements)(env, flat, elements, FDNN_JNI_ABORT);
   jfloatArray result = nullptr;
   if (rc)
-    throw_status(env, rc);
+    throw_status(env, rc, out ? nullptr : "out of host memory for the result block");
   else
     result = to_java(env, out, len);
   if (len * sizeof(float) > kScratchMax) t_scratch.release();

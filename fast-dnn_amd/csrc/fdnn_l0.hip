@@ -525,7 +525,7 @@ struct L0MfmaCfg {
 //   unless both neighbouring indices hold the same table byte.  Products below 2^-126 add at most 432 * 2^-150, covered by
 //   the 1e-30 in D; a NaN anywhere flags.  (With the classical bound 218 u S alone 1.9 % of the outputs were flagged;
 //   A is small because partial sums are random-walk sized, S is not.)
-constexpr int kScreenEvery = FDNN_L0_SCREEN_EVERY;
+[[maybe_unused]] constexpr int kScreenEvery = FDNN_L0_SCREEN_EVERY;
 template <int BK, int WFR, bool TAP, bool SCREEN = false>
 __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
 #if defined(__HIP_DEVICE_COMPILE__)
