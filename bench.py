@@ -440,7 +440,7 @@ def main() -> None:
         # the few outputs the fusion could change) -- priced against the fp32 MFMA peak; in the scoring loop the overlapped
         # batches use the all-VALU chain kernel instead
         add("l0", "layer 0: " + ("l0_mfma_kernel (fused flavour, fp32 MFMA)" if args.l0_fma else
-            "l0_xnorm_kernel + l0_mfma_kernel<screen> + l0_fix_kernel (canonical numerics: fused chains on the fp32 MFMA, "
+            "l0_mfma_kernel<screen> + l0_fix_kernel (canonical numerics: fused chains on the fp32 MFMA, "
             "rigorous error bound, exact unfused recomputation of ~0.4 % of the outputs)"),
             "mfma", 2.0 * 432 * 2048 * n, 157.3, "TFLOP/s", 1e12,
             4 * (432 * n + 432 * 2048) + 2048 * n, "l0_mfma_kernel")

@@ -75,7 +75,6 @@ struct fdnn_ctx {
   float *d_xt = nullptr;          // [4][l0_j_pad][xt_ld] layer-0 frame image (shifted, scaled, chain-major)
   int xt_ld = 0;
   float *d_l0park = nullptr;      // [xt_ld][l0_h_ld] partial chain sums parked by the layer-0 kernel
-  float *d_xnorm = nullptr;       // [cap] frame norms of the screened layer-0 path
   uint32_t *d_scr_count = nullptr;  // [frame tiles x node tiles] flagged outputs per tile (kept zero between launches)
   uint16_t *d_scr_list = nullptr;   // [tiles][kL0ScreenCap]
   int8_t *d_act[2] = {nullptr, nullptr};  // [n_pad][act_ld] ping/pong, s8 = u8-128

@@ -33,7 +33,6 @@ struct L0Params {
   // canonical flavour, screened path (large batches, no taps): the FUSED chains on the fp32 MFMA for every output,
   // a rigorous bound on |fused - unfused| per output, and the exact unfused chains for the few outputs whose
   // table index the difference could change (fdnn_l0.hip: "screened").  All null/0 = path not available.
-  float *xnorm;        // [n] scratch: upper bound of ||(x_f + shift) * scale||_2
   const float *wnorm;  // [H] upper bound of ||w_n||_2 (model load)
   uint32_t *scr_count; // [tiles] flagged outputs per 128 x 128 tile; zero between launches
   uint16_t *scr_list;  // [tiles][kL0ScreenCap] tile-local indices frame_row * 128 + node_col

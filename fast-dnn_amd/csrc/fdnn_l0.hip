@@ -578,13 +578,21 @@ __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
     sh = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sh_rsrc, k * 4, 0, 0));
     sc = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sc_rsrc, k * 4, 0, 0));
   };
+  // SCREEN: ||(x_f + shift) * scale||^2 of the rows this thread stages, one k quad per chunk (the frame half of the
+  // bound; every element passes through lstore exactly once).  Computed here, by all 16 node tiles of a frame tile over
+  // again, it costs eight fma per chunk and thread; as a kernel of its own (round 2's first version) 8 us + a launch.
+  float nsq[SCREEN ? XPT : 1];
+#pragma unroll
+  for (int q = 0; q < (SCREEN ? XPT : 1); ++q) nsq[q] = 0.0f;
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < XPT; ++q) {
       float *dst = smem + buf * kStage + (srow + q * RPQ) * LD + skq;
       // ApplyShiftAndScale: add, then multiply (dnn.cc:184-187); quad order [k0 k2 k1 k3]
-      *reinterpret_cast<float2 *>(dst) = make_float2((sx[q].x + sh.x) * sc.x, (sx[q].z + sh.z) * sc.z);
-      *reinterpret_cast<float2 *>(dst + 2) = make_float2((sx[q].y + sh.y) * sc.y, (sx[q].w + sh.w) * sc.w);
+      const float v0 = (sx[q].x + sh.x) * sc.x, v1 = (sx[q].y + sh.y) * sc.y, v2 = (sx[q].z + sh.z) * sc.z, v3 = (sx[q].w + sh.w) * sc.w;
+      *reinterpret_cast<float2 *>(dst) = make_float2(v0, v2);
+      *reinterpret_cast<float2 *>(dst + 2) = make_float2(v1, v3);
+      if (SCREEN) nsq[q] = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, nsq[q]))));
     }
 #pragma unroll
     for (int q = 0; q < WPT; ++q) {
@@ -655,9 +663,21 @@ __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
   // SCREEN: the tile's list of flagged outputs lives behind the byte tile (TF * TS bytes) in the dead staging ring
   uint32_t *scr_n = reinterpret_cast<uint32_t *>(tile + TF * TS);
   uint16_t *scr_l = reinterpret_cast<uint16_t *>(tile + TF * TS + 16);
-  static_assert(!SCREEN || TF * TS + 16 + 2 * kL0ScreenCap <= 2 * kStage * 4, "flag list must fit in the staging ring");
+  float *xn_s = reinterpret_cast<float *>(tile + TF * TS + 16 + 2 * kL0ScreenCap);  // [TF] frame norms, rounded up
+  static_assert(!SCREEN || TF * TS + 16 + 2 * kL0ScreenCap + TF * 4 <= 2 * kStage * 4, "flag list and norms must fit in the staging ring");
+  static_assert((TF * TS + 16 + 2 * kL0ScreenCap) % 4 == 0, "norm array alignment");
   if (SCREEN) {
     if (tid == 0) *scr_n = 0;
+    // the QPR threads of a row sit in adjacent lanes: sum their partial squares, one of them publishes the norm.  The
+    // float (fma) sum of D squares is within D u of the true one, the square root and these adds a few u more: rounded
+    // up by (1 + 2 D u + 1e-5)  (D <= 2^20 by the loader)
+#pragma unroll
+    for (int q = 0; q < XPT; ++q) {
+      float s2 = nsq[SCREEN ? q : 0];
+#pragma unroll
+      for (int off = 1; off < QPR; off <<= 1) s2 += __shfl_xor(s2, off);
+      if (tid % QPR == 0) xn_s[srow + q * RPQ] = sqrtf(s2) * (1.00001f + 2.0f * 5.9604645e-8f * static_cast<float>(p.D));
+    }
     __syncthreads();
   }
   // SCREEN, pass 1 (branch free): one flag bit per output of this lane (bit 16 s + r).  The frame norms of the lane's
@@ -693,7 +713,7 @@ __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
       for (int r = 0; r < 16; ++r) {
         const int row = wf * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
         const float t = (((acc[s][0][r] + acc[s][0][16 + r]) + (acc[s][1][r] + acc[s][1][16 + r])) + bias) * 100.0f;  // as above
-        const float xn = f0 + row < p.n ? p.xnorm[f0 + row] : 0.0f;
+        const float xn = f0 + row < p.n ? xn_s[row] : 0.0f;
         const float F = (fabsf(acc[s][0][r]) + fabsf(acc[s][0][16 + r])) + (fabsf(acc[s][1][r]) + fabsf(acc[s][1][16 + r]));
         constexpr float kW = 2.0f * (BK / 4) * kScreenEvery;  // 2 x steps per window: both chains' partial sums
         const float E = fmaf(kW, absacc[SCREEN ? r : 0], fmaf((kW + 1.0f) * xn, wn_bound, 8.0f * (F + fabsf(bias)))) * kScreenE;
@@ -752,24 +772,6 @@ __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
           *reinterpret_cast<const uint4 *>(tile + row * TS + c16);
   }
 #endif
-}
-
-// ||(x_f + shift) * scale||_2 per frame, rounded UP (one wave per frame): the frame half of the screened path's bound.
-__global__ __launch_bounds__(256) void l0_xnorm_kernel(const float *x, const float *shift, const float *scale, float *xnorm, int n, int D) {
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (f >= n) return;
-  float s = 0.0f;
-  for (int k = 4 * lane; k < D; k += 256) {  // D is a multiple of 4
-    const v4f v = (*reinterpret_cast<const v4f *>(x + static_cast<size_t>(f) * D + k) + *reinterpret_cast<const v4f *>(shift + k)) *
-                  *reinterpret_cast<const v4f *>(scale + k);
-    s = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, s))));
-  }
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-  // the float (fma) sum of D squares is within D u of the true one, the square root and the shuffles' adds a few u more:
-  // rounded up by (1 + 2 D u + 1e-5)  (D <= 2^20 by the loader)
-  if (lane == 0) xnorm[f] = sqrtf(s) * (1.00001f + 2.0f * 5.9604645e-8f * static_cast<float>(D));
 }
 
 // element `src` (0..3) of every aligned group of four lanes, to all four: a DPP quad_perm move, no LDS traffic
@@ -878,7 +880,7 @@ void launch_mfma(const L0Params &p, hipStream_t s) {
   hipLaunchKernelGGL(p.tap_lin ? k_tap : k_prod, grid, dim3(Cfg::THREADS), Cfg::LDS, s, p);
 }
 
-// Canonical numerics through the screened path: frame norms, fused chains + screening, exact recomputation of the flagged.
+// Canonical numerics through the screened path: fused chains + screening (frame norms included), exact recomputation of the flagged.
 void launch_screened(const L0Params &p, hipStream_t s) {
   using Cfg = L0MfmaCfg<32, 4>;
   static_assert(Cfg::TF == 128 && Cfg::TN == 128, "l0_fix_kernel assumes 128 x 128 tiles");
@@ -891,7 +893,6 @@ void launch_screened(const L0Params &p, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_scr), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
-  hipLaunchKernelGGL(l0_xnorm_kernel, dim3((p.n + 3) / 4), dim3(256), 0, s, p.x, p.shift, p.scale, p.xnorm, p.n, p.D);
   const int node_tiles = (p.H + 127) / 128, frame_tiles = (p.n_rows + 127) / 128;
   hipLaunchKernelGGL(k_scr, dim3(l0_grid(node_tiles, frame_tiles)), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   hipLaunchKernelGGL(l0_fix_kernel, dim3(node_tiles * frame_tiles), dim3(256), 2 * sizeof(float) * p.D, s, p);
@@ -924,7 +925,7 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   const double tile64_us = p.n_rows <= 320    ? 23.0 * work
                            : p.n_rows <= 1200 ? (17.0 + 0.032 * p.n_rows) * work
                                               : 20.0 + 0.0355 * work * (p.H / 2048.0) * p.n_rows;
-  const bool can_screen = !p.fma && !no_screen && p.kernel == 0 && !p.tap_lin && p.xnorm && p.wnorm && p.scr_count && p.scr_list && p.n >= 2048;
+  const bool can_screen = !p.fma && !no_screen && p.kernel == 0 && !p.tap_lin && p.wnorm && p.scr_count && p.scr_list && p.n >= 2048;
   const bool can_chain = !p.fma && p.xt && p.wt && p.kernel != 2 && !(classic && p.kernel == 0);
   if (can_screen && screened_us < (can_chain ? chain_us : tile64_us) && screened_us < tile64_us) {
     launch_screened(p, s);

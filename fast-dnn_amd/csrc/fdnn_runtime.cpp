@@ -132,7 +132,6 @@ void destroy_ctx(fdnn_ctx *c) {
   hipFree(c->d_x);
   hipFree(c->d_xt);
   hipFree(c->d_l0park);
-  hipFree(c->d_xnorm);
   hipFree(c->d_scr_count);
   hipFree(c->d_scr_list);
   hipFree(c->d_act[0]);
@@ -171,9 +170,8 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
   alloc(reinterpret_cast<void **>(&c->d_x), sizeof(float) * np * h.in_dim);
   c->xt_ld = round_up(c->cap, 128);
   alloc(reinterpret_cast<void **>(&c->d_xt), sizeof(float) * 4 * size_t(m->l0_j_pad) * c->xt_ld);
-  {  // screened layer-0 path: frame norms + the per-tile lists of outputs to recompute exactly
+  {  // screened layer-0 path: the per-tile lists of outputs to recompute exactly
     const size_t tiles = size_t(c->xt_ld / 128) * size_t((h.hidden + 127) / 128);
-    alloc(reinterpret_cast<void **>(&c->d_xnorm), sizeof(float) * size_t(c->xt_ld));
     alloc(reinterpret_cast<void **>(&c->d_scr_count), sizeof(uint32_t) * tiles);
     alloc(reinterpret_cast<void **>(&c->d_scr_list), sizeof(uint16_t) * tiles * fdnn::kL0ScreenCap);
     if (e == hipSuccess) e = hipMemset(c->d_scr_count, 0, sizeof(uint32_t) * tiles);
@@ -293,7 +291,6 @@ void run_layer0(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) 
   l0.xt = c->d_xt;
   l0.wt = m->d_w0t;
   l0.park = c->d_l0park;
-  l0.xnorm = c->d_xnorm;
   l0.wnorm = m->d_w0norm;
   l0.scr_count = c->d_scr_count;
   l0.scr_list = c->d_scr_list;
