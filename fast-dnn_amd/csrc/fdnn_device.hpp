@@ -32,11 +32,16 @@ __device__ __forceinline__ void glds16(const void *g, void *lds_wave_base) {
 #endif
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
+// The s_nop is part of the store: a vector-memory store of more than 8 bytes reads its data registers a cycle after
+// issue, and a vector-ALU write to them in the very next slot corrupts what is stored.  For a store it emits itself the
+// compiler's hazard recognizer inserts that wait state; inside inline asm it cannot see the store, and it is free to
+// reuse the registers at once -- found when a rescheduled output epilogue wrote a few wrong exp(z) values per launch,
+// different ones from run to run (the rows' totals were right, their sums after the scale pass were not).
 __device__ __forceinline__ void store_wt(void *p, v4i v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_wt(void *p, v4f_t v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_wt(void *p, v2f_t v) {
   asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");

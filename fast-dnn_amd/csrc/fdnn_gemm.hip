@@ -575,6 +575,39 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
             // PLAIN: the whole group of 4 nodes is inside or outside the layer (rows % 4 == 0)
             const bool in4 = nb < p.rows;
             float e[4];
+            if constexpr (PLAIN && FAST) {
+              // The dense / batched-lazy production instances: the same operations per element as the loop below (cvt,
+              // x * y, two fma of the exact division, + bias, * log2 e, v_exp_f32), written on pairs so that the five
+              // multiplies / fmas / adds go out as packed instructions -- left to itself the compiler packs the hidden
+              // layers' epilogue but not this one (965 -> 485 vector instructions per lane and tile).
+              typedef float v2f_e __attribute__((ext_vector_type(2)));
+              const v2f_e rcp2 = {p.rcp_coef, p.rcp_coef}, coef2 = {p.coef, p.coef};
+              const v2f_e log2e2 = {1.44269504088896340736f, 1.44269504088896340736f};
+#pragma unroll
+              for (int h2 = 0; h2 < 2; ++h2) {
+                const v2f_e x = {static_cast<float>(acc[mi][ni][g * 4 + 2 * h2]), static_cast<float>(acc[mi][ni][g * 4 + 2 * h2 + 1])};
+                const v2f_e q0 = x * rcp2;
+                const v2f_e r = __builtin_elementwise_fma(-q0, coef2, x);
+                v2f_e z = __builtin_elementwise_fma(r, rcp2, q0) + v2f_e{bj[2 * h2], bj[2 * h2 + 1]};
+                if (MASKED) {
+                  if (((mbits >> (16 * h2)) & 0xffu) == 0) z.x = 0.0f;
+                  if (((mbits >> (16 * h2 + 8)) & 0xffu) == 0) z.y = 0.0f;
+                }
+                const v2f_e y = z * log2e2;
+                if (ANYW || (FDNN_GEMM_DEBUG & 256)) {
+                  e[2 * h2] = nb + 2 * h2 < p.rows ? __builtin_amdgcn_exp2f(y.x) : 0.0f;
+                  e[2 * h2 + 1] = nb + 2 * h2 + 1 < p.rows ? __builtin_amdgcn_exp2f(y.y) : 0.0f;
+                } else {
+                  // nodes past the layer's width (zero weights, zero bias: z = 0, e = 1) must not reach the row sum: one
+                  // packed multiply by 0 / 1 per pair instead of a select per element
+                  const v2f_e ev = v2f_e{__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)} * v2f_e{in4 ? 1.0f : 0.0f, in4 ? 1.0f : 0.0f};
+                  e[2 * h2] = ev.x;
+                  e[2 * h2 + 1] = ev.y;
+                }
+              }
+#pragma unroll
+              for (int q = 0; q < 4; ++q) psum[ni] += e[q];
+            } else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int av = acc[mi][ni][g * 4 + q];
