@@ -618,6 +618,11 @@ __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
       // fenced: left to itself the scheduler overlaps these reads with the next MFMAs by copying the accumulators they
       // are about to overwrite (289 spilled registers)
       __builtin_amdgcn_sched_barrier(0);
+      // the reads below are inline asm: the compiler's hazard recognizer does not see that they consume matrix-pipe
+      // results (a 16-pass MFMA's destination may not be read by the vector ALU for 18 wait states).  The previous
+      // chunk's last MFMA is a staging pass and a barrier away already; these 20 idle slots make that independent of
+      // how the code in between is scheduled.
+      asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         // eight in-place v_add_f32 with |.| on the accumulator operand (written as asm: through fabsf() the compiler
