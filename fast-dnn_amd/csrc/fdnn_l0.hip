@@ -787,12 +787,16 @@ __device__ __forceinline__ float quad_bcast(float v) {
 
 // The exact canonical chains (four k-mod-4 partial sums, multiply and add rounded separately, (l0+l1)+(l2+l3), bias,
 // table: dnn.cc:219-286) for the outputs l0_mfma_kernel<SCREEN> listed -- all 128 x 128 of them when a tile's list
-// overflowed.  One 256-thread workgroup per tile, FOUR lanes per listed output: lane c is chain c.  The four lanes walk
+// overflowed.  One workgroup per tile, FOUR lanes per listed output: lane c is chain c.  The four lanes walk
 // the two operand rows 64 contiguous bytes per load instruction -- lane c fetches the quad of k-step 4i + c (x with shift
 // and scale applied, w) -- and each step's quad is then handed round with quad broadcasts, chain c keeping element c.
 // (One lane per output reading 16 bytes of its own rows per load is address-processing bound: every (output, k-quad) is
 // its own 16-byte segment -- 66 us for 0.4 % of the outputs.)
-__global__ __launch_bounds__(256) void l0_fix_kernel(L0Params p) {
+#ifndef FDNN_L0_FIX_THREADS
+#define FDNN_L0_FIX_THREADS 512  // 128 outputs per pass: 40.1 us against 42.6 (256), 45.4 (128), 71 (1024) for 82 000 outputs
+#endif
+constexpr int kFixThreads = FDNN_L0_FIX_THREADS;
+__global__ __launch_bounds__(kFixThreads) void l0_fix_kernel(L0Params p) {
   constexpr int TF = 128, TN = 128;
   typedef float v4f __attribute__((ext_vector_type(4)));
   const int node_tiles = (p.H + TN - 1) / TN;
@@ -806,13 +810,13 @@ __global__ __launch_bounds__(256) void l0_fix_kernel(L0Params p) {
   const int quads = p.D / 4;  // D is a multiple of 4
   extern __shared__ __attribute__((aligned(16))) float fix_smem[];  // shift[D], scale[D]
   float *sh_s = fix_smem, *sc_s = fix_smem + p.D;
-  for (int k = tid; k < p.D; k += 256) {
+  for (int k = tid; k < p.D; k += kFixThreads) {
     sh_s[k] = p.shift[k];
     sc_s[k] = p.scale[k];
   }
   __syncthreads();
   int done = 0;
-  for (int base = 0; base < total; base += 64) {  // (uniform trip count: the quad broadcasts need all four lanes present)
+  for (int base = 0; base < total; base += kFixThreads / 4) {  // (uniform trip count: the quad broadcasts need all four lanes present)
     const int o = base + (tid >> 2);
     const bool valid = o < total;
     const int local = valid ? (all ? o : p.scr_list[static_cast<size_t>(tile_id) * kL0ScreenCap + o]) : 0;
@@ -900,7 +904,7 @@ void launch_screened(const L0Params &p, hipStream_t s) {
   }
   const int node_tiles = (p.H + 127) / 128, frame_tiles = (p.n_rows + 127) / 128;
   hipLaunchKernelGGL(k_scr, dim3(l0_grid(node_tiles, frame_tiles)), dim3(Cfg::THREADS), Cfg::LDS, s, p);
-  hipLaunchKernelGGL(l0_fix_kernel, dim3(node_tiles * frame_tiles), dim3(256), 2 * sizeof(float) * p.D, s, p);
+  hipLaunchKernelGGL(l0_fix_kernel, dim3(node_tiles * frame_tiles), dim3(kFixThreads), 2 * sizeof(float) * p.D, s, p);
 }
 
 }  // namespace
