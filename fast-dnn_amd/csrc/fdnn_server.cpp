@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -133,7 +134,14 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
   c->n = n;
   c->last = -1;
   const bool small = n <= kSmallBatch;
-  c->l0_chain_only = !small;  // see fdnn_ctx: the overlapped scale pass needs room beside layer 0
+  // Large batches, two ways (FDNN_SERVER_OVERLAP=0|1): "overlap" = all-VALU chain layer 0 with the previous batch's
+  // soft-max scale as a background kernel underneath it; "serial" = the screened matrix-pipe layer 0 (65 us shorter) and
+  // the ordinary full-grid scale kernel in line.  The matrix kernel admits nothing beside it.
+  static const bool overlap = [] {
+    const char *e = std::getenv("FDNN_SERVER_OVERLAP");
+    return e ? std::atoi(e) != 0 : true;
+  }();
+  c->l0_chain_only = !small && overlap;  // see fdnn_ctx: the overlapped scale pass needs room beside layer 0
   hipStream_t cs = small ? sl.stream : s->s_main;
   if (after) HIP_TRY(hipStreamWaitEvent(cs, after, 0));
   HIP_TRY(fdnn::ctx_enter(c, cs));
@@ -155,13 +163,13 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
       if (rc) break;
       if (!first) HIP_TRY(hipStreamWaitEvent(cs, sl.tail_done, 0));
       rc = fdnn::run_output(c, 0, ch.second, d_masks ? d_masks + size_t(ch.first) * O : nullptr, d_out + size_t(ch.first) * O, cs,
-                            nullptr, nullptr, s->s_tail, sl.gemm_done);
+                            nullptr, nullptr, overlap ? s->s_tail : nullptr, overlap ? sl.gemm_done : nullptr);
       if (rc) break;
-      HIP_TRY(hipEventRecord(sl.tail_done, s->s_tail));
+      HIP_TRY(hipEventRecord(sl.tail_done, overlap ? s->s_tail : cs));
       first = false;
     }
     c->n = n;
-    end = s->s_tail;
+    end = overlap ? s->s_tail : cs;
   }
   fdnn::ctx_leave(c, end);
   if (rc) return rc;
