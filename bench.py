@@ -410,13 +410,18 @@ def main() -> None:
             except Exception:
                 continue
 
-        def traffic_of(prefix):
+        def traffic_of(prefixes):
+            """HBM bytes per launch from the committed PMC summary; several prefixes = the kernels of one launch group, summed."""
             if n != FRAMES_PER_GPU:
                 return None
-            for name, c in pmc.items():
-                if name.startswith(prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                    return int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1000)  # bytes per launch
-            return None
+            total, found = 0, False
+            for prefix in ([prefixes] if isinstance(prefixes, str) else prefixes):
+                for name, c in pmc.items():
+                    if name.startswith(prefix) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                        total += int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1000)
+                        found = True
+                        break
+            return total if found else None
 
         step_ms = elapsed / steps * 1e3
         kinds = []
@@ -443,7 +448,7 @@ def main() -> None:
             "l0_mfma_kernel<screen> + l0_fix_kernel (canonical numerics: fused chains on the fp32 MFMA, "
             "rigorous error bound, exact unfused recomputation of ~0.4 % of the outputs)"),
             "mfma", 2.0 * 432 * 2048 * n, 157.3, "TFLOP/s", 1e12,
-            4 * (432 * n + 432 * 2048) + 2048 * n, "l0_mfma_kernel")
+            4 * (432 * n + 432 * 2048) + 2048 * n, "l0_mfma_kernel" if args.l0_fma else ("l0_mfma_kernel", "l0_fix_kernel"))
         add("hidden_gemm", "qgemm_kernel<hidden> (int8 MFMA 32x32x32, 2048x2048 layer + dequant/bias/sigmoid-table epilogue)",
             "mfma", 2.0 * 2048 * 2048 * n, INT8_PEAK_TOPS, "TOP/s", 1e12, 2048 * 2048 + 2 * n * 2048, "qgemm_kernel hidden")
         add("output_gemm", "qgemm_kernel<output> (int8 MFMA, 8000x2048 layer + dequant/bias/exp epilogue, 32 KB of exp(z) per frame out)",
