@@ -3,7 +3,7 @@ width x4, hidden x16, any output width), weight scales from no saturating pairs 
 saturating, both layer-0 flavours, random batch sizes across every kernel-selection branch, random masks.
 Checked per case: every layer's u8 activations and int32 accumulators through the tap kernels
 (bit-exact), the production kernels' last hidden layer (hiddenActivations, bit-exact), dense and
-lazy soft-max (<= 2e-6), and the dense result through the scoring loop (bit-identical to the call).
+lazy soft-max (<= 2e-6), and the dense and masked results through the scoring loop (bit-identical to the calls).
   python tools/fuzz_parity.py [cases] [seed]      (run on the GPU box)"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -68,8 +68,11 @@ for case in range(cases):
     ctx.delete()
     srv = api.ScoringServer(dnn, max(n, 64), 2)
     t, o = srv.submit(x)
+    tm, om = srv.submit(x, masks)  # the lazy contract through the loop, coalesced with the dense request
     srv.wait(t)
+    srv.wait(tm)
     assert np.array_equal(o, got, equal_nan=True), (tag, "scoring loop")
+    assert np.array_equal(om, lazy, equal_nan=True), (tag, "scoring loop, masked")
     srv.close()
     dnn.delete()
     orc.close()
