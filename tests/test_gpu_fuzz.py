@@ -19,3 +19,13 @@ def test_random_nets_and_batch_sizes_match_the_oracle(seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "80", str(seed)],
                        capture_output=True, text=True, timeout=900, env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
     assert r.returncode == 0 and "fuzz ok: 80 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_random_batch_sizes_on_the_full_net():
+    """16 batch sizes (half of them on the edges of a kernel-selection rule, half anywhere in 1..20 000) on the
+    432 -> 7x2048 -> 8000 net: the oracle scores a random sample of each batch (frames are independent); last
+    hidden layer u8 bit-exact, dense and lazy soft-max <= 2e-6, rows sum to one."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_net_sizes.py"), "16", "21"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, GRAFT_REPO_ROOT=ROOT))
+    assert r.returncode == 0 and "net-size fuzz ok: 16 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
