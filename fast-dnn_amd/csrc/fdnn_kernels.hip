@@ -83,7 +83,11 @@ __device__ __forceinline__ void normalize_row(const float *out, float *dst, cons
 __global__ __launch_bounds__(256) void normalize_kernel(const float *out, float *dst, const float *partial, int n, int partial_ld,
                                                         int rows, int n_partial) {
   __shared__ float red[4];
-  normalize_row<false>(out, dst, partial, blockIdx.x, partial_ld, rows, n_partial, red);
+#ifndef FDNN_NORM_NT
+#define FDNN_NORM_NT 0  // non-temporal here too (same box, tools/kstat.py): this pass 105 -> 118 us, the kernels after it
+                        // (whose operands it no longer evicts) -12 us together -- nothing in it
+#endif
+  normalize_row<(FDNN_NORM_NT != 0)>(out, dst, partial, blockIdx.x, partial_ld, rows, n_partial, red);
 }
 
 // The same pass as a BACKGROUND kernel for the server loop: a fixed, small grid of workgroups that
