@@ -239,3 +239,45 @@ def test_very_large_batches_run_in_chunks(mid_model_path):
     assert np.abs(lz[sel].cpu().numpy() - want_lazy).max() <= TIGHT
     srv.close()
     dnn.delete()
+
+
+def test_create_and_free_cycles_return_device_memory(mid_model_path):
+    """Models, lazy contexts, scoring loops (device and host side) and device groups created and freed
+    in a loop: device memory in use must come back to where it started (hipMemGetInfo through torch)."""
+    import torch
+
+    x = F.synth_features(700, 432, seed=9)
+
+    def cycle():
+        dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+        dnn.calculate(x)
+        ctx = dnn.getNewLazyContext(700)
+        ctx.calculateUntilOutput(x)
+        ctx.calculateForOutputNodes(np.ones(dnn.outputDimension(), dtype=np.int8))
+        ctx.delete()
+        srv = api.ScoringServer(dnn, 2048, 3)
+        t, _ = srv.submit(x)
+        srv.wait(t)
+        xd = torch.from_numpy(x).cuda()
+        od = torch.empty((700, dnn.outputDimension()), dtype=torch.float32, device="cuda")
+        srv.wait(srv.submit_device(xd.data_ptr(), 700, od.data_ptr()))
+        srv.close()
+        dnn.enableBatcher(1024, 2, 0)
+        dnn.calculate(x[:100])
+        dnn.delete()
+        grp = api.DeviceGroup(mid_model_path, [0, 0])
+        grp.calculate(x[:64])
+        grp.delete()
+        del xd, od
+
+    for _ in range(3):
+        cycle()  # pools, caches and the allocator's own slack settle
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free0, _total = torch.cuda.mem_get_info()
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free1, _total = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of device memory did not come back after 25 create/free cycles"
