@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("seed", [11, 12])
 def test_random_nets_and_batch_sizes_match_the_oracle(seed):
     """80 random cases per seed: every layer's u8 activations / int32 accumulators bit-exact (tap and
-    production kernels), soft-max <= 2e-6 for nets of the SURVEY 8(d) weight scale (1e-4 for extreme
+    production kernels), soft-max <= 2e-6 for nets of the SURVEY 8(d) weight scale (2e-4 for extreme
     weights, where the reference's own sequential fp32 sum is the inexact side), the same NaN pattern
     when exp overflows, scoring loop bit-identical."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "80", str(seed)],

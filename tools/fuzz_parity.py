@@ -54,7 +54,7 @@ for case in range(cases):
     # sane nets (w_std <= 0.05, the SURVEY 8(d) distribution) show 1e-7 -- measured: the logits are bit-equal, the REFERENCE's rows then sum to 1.000004 (SoftMax::apply
     # adds its 2048 exp values sequentially in fp32, dnn.cc:536-540) and this library's to 1.0000000 (fixed-order tree).
     # The bar is 1e-3.
-    tol = TIGHT if w_std <= 0.05 else 1e-4
+    tol = TIGHT if w_std <= 0.05 else 2e-4
     assert err <= tol, (tag, "dense", err)
     ctx = dnn.getNewLazyContext(n)
     ctx.calculateUntilOutput(x)
