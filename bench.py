@@ -91,11 +91,14 @@ def host_info() -> dict:
 
 
 def cpu_baseline(model_path: str, frames: int = 100) -> dict:
-    """The reference algorithm (oracle SSE4.1 port, frame-block 8) on this host: a native pthread
-    harness (oracle/fdnn_oracle.c: orc_bench_threads), no interpreter in the timed region -- one
-    thread, then one thread per usable core, each scoring independent 100-frame utterances with a
-    private context per call (the reference's own concurrency model,
-    MultiThreadedStressTest.java:48-61; timed region as in the reference CLI, dnn.cc:64-71)."""
+    """The reference on this host's cores, next to the GPU number.  Where oracle/_ref is present (the reference's own
+    dnn.cc / float_dnn.cc compiled by oracle/Makefile; it travels with the repo as a .so) the figure reported as
+    `value` is THE REFERENCE ITSELF (kind "reference"): a native pthread harness (oracle/ref_tap.cpp:
+    ref_bench_threads), one thread per usable core, every thread scoring independent 100-frame utterances with a
+    fresh CalculationContext per call (jni_dnn.cc:49-51; concurrency model of MultiThreadedStressTest.java:48-61;
+    timed region = context construction + Calculate as in the reference CLI, dnn.cc:64-71).  The oracle's SSE4.1
+    port (oracle/fdnn_oracle.c: orc_bench_threads, frame block 8) is timed the same way beside it and is the
+    fallback (kind "port") where the compiled reference is absent.  No interpreter in any timed region."""
     import ctypes as C
 
     from fast_dnn_amd import formats as F
@@ -107,58 +110,75 @@ def cpu_baseline(model_path: str, frames: int = 100) -> dict:
     L.orc_bench_threads.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
     x = F.synth_features(frames, seed=900)
     xp = x.ctypes.data_as(C.POINTER(C.c_float))
+    dim = int(x.shape[1])
 
-    def run(threads, utts):
+    def run_port(threads, utts):
         per = (C.c_double * threads)()
         wall = L.orc_bench_threads(orc.h, xp, frames, 8, 1, threads, utts, per)
         if wall <= 0:
             raise RuntimeError("oracle thread harness failed")
         return wall, list(per)
 
-    run(1, 1)  # warm-up
-    one = float(np.median([frames / run(1, 1)[0] for _ in range(3)]))
     host = host_info()
     usable = host.get("physical_cores") or host["logical_cpus"]
     if host.get("cgroup_cpu_quota"):
         usable = max(1, min(usable, int(host["cgroup_cpu_quota"])))
     usable = min(usable, host["logical_cpus"])
     utts = 2
-    # the host is shared (cgroup quota, other tenants): three passes, the median one is reported (all three in the line)
-    passes = sorted((run(usable, utts) for _ in range(3)), key=lambda r: r[0])
-    wall, per = passes[1]
-    many = usable * utts * frames / wall
-    # the reference itself (oracle/_ref, compiled from the reference's own sources where they were available), one thread,
-    # same utterance: times the real code beside the port and checks that the two agree on this sample
-    ref_one = ref_diff = None
+
+    def measure(run):
+        run(1, 1)  # warm-up
+        one = sorted(frames / run(1, 1)[0] for _ in range(3))
+        # the host is shared (cgroup quota, other tenants): three passes, min / median / max all in the line
+        passes = sorted((run(usable, utts) for _ in range(3)), key=lambda r: r[0])
+        rates = sorted(usable * utts * frames / w for w, _ in passes)
+        per = passes[1][1]
+        return {"one": one, "rates": rates, "slow": max(per), "fast": min(per)}
+
+    port = measure(run_port)
+    ref = ref_diff = None
     try:
         from oracle.oracle import RefLib
 
-        ref = RefLib().load(model_path)
-        y_ref = ref.calculate(x, 8)  # warm-up
-        ts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            y_ref = ref.calculate(x, 8)
-            ts.append(time.perf_counter() - t0)
-        ref_one = frames / float(np.median(ts))
-        ref_diff = float(np.abs(y_ref - orc.calculate(x, 8)).max())
-        ref.close()
-    except (OSError, FileNotFoundError):
-        pass
-    return {
-        "value": round(many, 1), "unit": "frames/s", "cores": usable, "kind": "port",
-        "value_1thread": round(one, 1),
-        "reference_value_1thread": None if ref_one is None else round(ref_one, 1),
+        lib = RefLib()
+        lib.L.ref_bench_threads.restype = C.c_double
+        lib.L.ref_bench_threads.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        rm = lib.load(model_path)
+
+        def run_ref(threads, utts_):
+            per = (C.c_double * threads)()
+            wall = lib.L.ref_bench_threads(rm.h, xp, frames, dim, 8, threads, utts_, per)
+            if wall <= 0:
+                raise RuntimeError("reference thread harness failed")
+            return wall, list(per)
+
+        ref = measure(run_ref)
+        ref_diff = float(np.abs(rm.calculate(x, 8) - orc.calculate(x, 8)).max())  # the two agree on this very sample
+        rm.close()
+    except (OSError, FileNotFoundError, AttributeError):
+        ref = None
+    main_ = ref if ref is not None else port
+    r3 = lambda v: round(float(v), 1)
+    out = {
+        "value": r3(main_["rates"][1]), "unit": "frames/s", "cores": usable, "kind": "reference" if ref is not None else "port",
+        "value_min_median_max": [r3(v) for v in main_["rates"]],
+        "value_1thread": r3(main_["one"][1]), "value_1thread_min_median_max": [r3(v) for v in main_["one"]],
+        "scaling_vs_1thread": round(main_["rates"][1] / main_["one"][1], 2),
+        "slowest_thread_s": round(main_["slow"], 3), "fastest_thread_s": round(main_["fast"], 3),
+        "port_value": r3(port["rates"][1]), "port_value_min_median_max": [r3(v) for v in port["rates"]],
+        "port_value_1thread": r3(port["one"][1]),
+        "reference_value": None if ref is None else r3(ref["rates"][1]),
+        "reference_value_1thread": None if ref is None else r3(ref["one"][1]),
+        "port_vs_reference_1thread": None if ref is None else round(port["one"][1] / ref["one"][1], 3),
         "reference_vs_port_max_abs_diff": ref_diff,
-        "scaling_vs_1thread": round(many / one, 2),
-        "value_passes": [round(usable * utts * frames / w, 1) for w, _ in passes],
-        "slowest_thread_s": round(max(per), 3), "fastest_thread_s": round(min(per), 3),
         "host": host,
-        "sample": f"oracle SSE4.1 port (pmaddubsw, frame-block 8) of the same net, native pthread harness: 3 x {frames}-frame "
-                  f"utterances on 1 thread (median), then 3 passes of {usable * utts} utterances on {usable} threads (one per physical core "
-                  f"within the cgroup quota; median pass reported), one context per call; every thread streams the 45 MB of weights once per 8-frame "
-                  f"block, so the multi-thread figure is bound by shared cache / memory bandwidth, not by core count",
+        "sample": f"{'the compiled reference (oracle/_ref: dnn.cc + float_dnn.cc, -O2 -msse4 -ffp-contract=off)' if ref is not None else 'oracle SSE4.1 port (pmaddubsw, frame-block 8)'}"
+                  f" on the same net, native pthread harness: 3 x one {frames}-frame utterance on 1 thread, then 3 passes of {usable * utts} "
+                  f"utterances on {usable} threads (one per physical core within the cgroup quota; min / median / max given, median = value), "
+                  f"a fresh context per call; every thread streams the 45 MB of weights once per 8-frame block, so the multi-thread "
+                  f"figure is bound by shared cache / memory bandwidth, not by core count",
     }
+    return out
 
 
 def main() -> None:

@@ -308,6 +308,18 @@ static inline float l0_dot(int D, const float *x, const float *w) {
   return (s0 + s1) + (s2 + s3);
 }
 
+/* The same chains as the reference runs them (dnn.cc:232-240): one __m128 accumulator, mulps then addps
+ * (this file is built -ffp-contract=off, so they stay two roundings), hadd, hadd = (l0+l1)+(l2+l3).
+ * Bit-identical to l0_dot's unfused branch; the timing harness uses it so that the port's layer 0 costs what
+ * the reference's does (the scalar loop made the port 15 % slower than the compiled reference on one thread). */
+static inline float l0_dot_sse(int D, const float *x, const float *w) {
+  __m128 sum = _mm_setzero_ps();
+  for (int k = 0; k < D; k += 4) sum = _mm_add_ps(sum, _mm_mul_ps(_mm_loadu_ps(x + k), _mm_loadu_ps(w + k)));
+  sum = _mm_hadd_ps(sum, sum);
+  sum = _mm_hadd_ps(sum, sum);
+  return _mm_cvtss_f32(sum);
+}
+
 /* SoftMax::apply -- dnn.cc:534-544: expf, sequential fp32 total, no max
  * subtraction. */
 static void softmax_apply(float *z, int n, float *scratch) {
@@ -359,7 +371,9 @@ int orc_hidden(const orc_model *m, const float *x_in, int n, int batch, int use_
   for (int b0 = 0; b0 < n; b0 += batch) {
     int nb = n - b0 < batch ? n - b0 : batch;
     for (int i = 0; i < H; ++i)
-      for (int j = 0; j < nb; ++j) lin[(size_t)j * H + i] = l0_dot(D, x + (size_t)(b0 + j) * D, L0->w + (size_t)i * D);
+      for (int j = 0; j < nb; ++j)
+        lin[(size_t)j * H + i] = (use_sse && !g_l0_fma) ? l0_dot_sse(D, x + (size_t)(b0 + j) * D, L0->w + (size_t)i * D)
+                                                       : l0_dot(D, x + (size_t)(b0 + j) * D, L0->w + (size_t)i * D);
     for (int j = 0; j < nb; ++j)
       for (int i = 0; i < H; ++i) {
         float v = lin[(size_t)j * H + i] + L0->bias[i]; /* AddBias dnn.cc:250-264 */
@@ -519,10 +533,16 @@ long long orc_risky_pairs(const orc_model *m, int j) {
 #include <time.h>
 
 typedef struct {
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  int state; /* 0 wait, 1 go, 2 abort */
+} orc_mt_start;
+
+typedef struct {
   const orc_model *m;
   const float *x;
   int n, batch, sse, utts;
-  pthread_barrier_t *start;
+  orc_mt_start *start;
   double seconds;
   int rc;
 } orc_mt_arg;
@@ -537,7 +557,14 @@ static void *orc_mt_worker(void *p) {
   orc_mt_arg *a = (orc_mt_arg *)p;
   const int O = a->m->layers[a->m->n_layers - 1].out_dim;
   float *out = (float *)malloc(sizeof(float) * (size_t)a->n * (size_t)O);
-  pthread_barrier_wait(a->start);
+  pthread_mutex_lock(&a->start->mu);
+  while (a->start->state == 0) pthread_cond_wait(&a->start->cv, &a->start->mu);
+  const int go = a->start->state == 1;
+  pthread_mutex_unlock(&a->start->mu);
+  if (!go) {
+    free(out);
+    return NULL;
+  }
   const double t0 = orc_now();
   a->rc = out ? 0 : -1;
   for (int u = 0; u < a->utts && !a->rc; ++u) a->rc = orc_calculate(a->m, a->x, a->n, a->batch, a->sse, out, NULL);
@@ -551,30 +578,32 @@ double orc_bench_threads(const orc_model *m, const float *x, int n, int batch, i
   if (threads < 1 || utts < 1) return -1.0;
   pthread_t *th = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
   orc_mt_arg *args = (orc_mt_arg *)calloc((size_t)threads, sizeof(orc_mt_arg));
-  pthread_barrier_t start;
-  pthread_barrier_init(&start, NULL, (unsigned)threads + 1);
+  orc_mt_start start;
+  pthread_mutex_init(&start.mu, NULL);
+  pthread_cond_init(&start.cv, NULL);
+  start.state = 0;
   int made = 0;
   for (int t = 0; t < threads; ++t) {
     args[t] = (orc_mt_arg){m, x, n, batch, use_sse, utts, &start, 0.0, 0};
     if (pthread_create(&th[t], NULL, orc_mt_worker, &args[t]) != 0) break;
     ++made;
   }
-  if (made != threads) { /* cannot release a barrier sized for `threads`: report failure */
-    for (int t = 0; t < made; ++t) pthread_cancel(th[t]);
-    free(th);
-    free(args);
-    return -1.0;
-  }
-  pthread_barrier_wait(&start);
+  /* every started thread is released (go, or abort when one could not be started) and joined:
+   * nothing is cancelled and nothing is freed under a running thread */
+  pthread_mutex_lock(&start.mu);
+  start.state = made == threads ? 1 : 2;
+  pthread_cond_broadcast(&start.cv);
+  pthread_mutex_unlock(&start.mu);
   const double t0 = orc_now();
-  int rc = 0;
-  for (int t = 0; t < threads; ++t) {
+  int rc = made == threads ? 0 : -1;
+  for (int t = 0; t < made; ++t) {
     pthread_join(th[t], NULL);
     rc |= args[t].rc;
     if (per_thread) per_thread[t] = args[t].seconds;
   }
   const double wall = orc_now() - t0;
-  pthread_barrier_destroy(&start);
+  pthread_cond_destroy(&start.cv);
+  pthread_mutex_destroy(&start.mu);
   free(th);
   free(args);
   return rc ? -1.0 : wall;

@@ -10,6 +10,8 @@
 // Two tricks, both compile-time only: `main` in dnn.cc is renamed so the CLI
 // entry does not clash, and `private` is made public for the reference's own
 // headers so the harness can read CalculationContext's scratch buffers.
+#include <pthread.h>
+#include <time.h>
 #include <x86intrin.h>
 #include <cassert>
 #include <chrono>
@@ -166,6 +168,81 @@ void ref_forward_taps(void *h, const float *x, int n, int dim, int batch, float 
     std::memcpy(probs, res->data(), sizeof(float) * (size_t)n * O);
     delete res;
   }
+}
+
+// Multi-thread timing harness over the reference itself (bench.py's cpu_baseline, kind "reference"): T native
+// threads share one immutable QuantizedDnn, each scores `utts` independent utterances of n frames with a fresh
+// CalculationContext per call -- exactly what the JNI shim does per calculate() (jni_dnn.cc:49-51), under the
+// concurrency model of MultiThreadedStressTest.java:48-61.  Timed region per call = context construction +
+// Calculate (the reference CLI's, dnn.cc:64-71) plus the private input copy the in-place ApplyShiftAndScale needs.
+// Returns wall seconds from the common start to the last finish (per-thread seconds in per_thread[T], may be
+// null), or -1 when a thread could not be started.
+namespace {
+struct RefMtShared {
+  pthread_mutex_t mu;
+  pthread_cond_t cv;
+  int state;  // 0 = wait, 1 = go, 2 = abort (a thread failed to start: nobody computes)
+};
+struct RefMtArg {
+  dnn::QuantizedDnn *q;
+  const float *x;
+  int n, dim, batch, utts;
+  RefMtShared *sh;
+  double seconds;
+};
+double ref_now() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return double(ts.tv_sec) + 1e-9 * double(ts.tv_nsec);
+}
+void *ref_mt_worker(void *p) {
+  RefMtArg *a = reinterpret_cast<RefMtArg *>(p);
+  pthread_mutex_lock(&a->sh->mu);
+  while (a->sh->state == 0) pthread_cond_wait(&a->sh->cv, &a->sh->mu);
+  const int state = a->sh->state;
+  pthread_mutex_unlock(&a->sh->mu);
+  if (state != 1) return nullptr;
+  const double t0 = ref_now();
+  for (int u = 0; u < a->utts; ++u) {
+    float *copy = dnn::AlignedAlloc<float>((size_t)a->n * a->dim);
+    std::memcpy(copy, a->x, sizeof(float) * (size_t)a->n * a->dim);
+    dnn::BatchData in(copy, (size_t)a->n, (size_t)a->dim, true);
+    dnn::CalculationContext ctx(a->q, (size_t)a->n, (size_t)a->batch);
+    dnn::BatchData *res = ctx.Calculate(in);
+    delete res;
+  }
+  a->seconds = ref_now() - t0;
+  return nullptr;
+}
+}  // namespace
+
+double ref_bench_threads(void *h, const float *x, int n, int dim, int batch, int threads, int utts, double *per_thread) {
+  if (threads < 1 || utts < 1) return -1.0;
+  RefMtShared sh;
+  pthread_mutex_init(&sh.mu, nullptr);
+  pthread_cond_init(&sh.cv, nullptr);
+  sh.state = 0;
+  std::vector<pthread_t> th((size_t)threads);
+  std::vector<RefMtArg> args((size_t)threads);
+  int made = 0;
+  for (int t = 0; t < threads; ++t) {
+    args[(size_t)t] = RefMtArg{reinterpret_cast<dnn::QuantizedDnn *>(h), x, n, dim, batch, utts, &sh, 0.0};
+    if (pthread_create(&th[(size_t)t], nullptr, ref_mt_worker, &args[(size_t)t]) != 0) break;
+    ++made;
+  }
+  pthread_mutex_lock(&sh.mu);
+  sh.state = made == threads ? 1 : 2;  // every started thread is released either way and joined below
+  pthread_cond_broadcast(&sh.cv);
+  pthread_mutex_unlock(&sh.mu);
+  const double t0 = ref_now();
+  for (int t = 0; t < made; ++t) pthread_join(th[(size_t)t], nullptr);
+  const double wall = ref_now() - t0;
+  pthread_cond_destroy(&sh.cv);
+  pthread_mutex_destroy(&sh.mu);
+  if (made != threads) return -1.0;
+  if (per_thread)
+    for (int t = 0; t < threads; ++t) per_thread[t] = args[(size_t)t].seconds;
+  return wall;
 }
 
 // Reference CLI (dnn.cc:20-84) callable in-process.
