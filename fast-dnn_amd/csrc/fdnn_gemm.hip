@@ -897,7 +897,28 @@ int qgemm_frame_tile(int rows_pad, int n) {
   return best;
 }
 
-void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s) { launch_qgemm<false>(p, s); }
-void launch_qgemm_output(const QGemmParams &p, hipStream_t s) { launch_qgemm<true>(p, s); }
+// Batches up to this many frames take the small-batch kernel (fdnn_small.hip) where the layer allows it.
+bool qgemm_small_pick(int rows_pad, int K, int n, int fastdiv, bool output) {
+  static const int small_max = [] {
+    const char *e = std::getenv("FDNN_SMALL_MAX");
+    return e ? std::atoi(e) : 1024;
+  }();
+  (void)rows_pad;
+  (void)output;
+  return n <= small_max && qgemm_small_ok(K, fastdiv);
+}
+
+void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s) {
+  if (p.small)
+    launch_qgemm_small_hidden(p, s);
+  else
+    launch_qgemm<false>(p, s);
+}
+void launch_qgemm_output(const QGemmParams &p, hipStream_t s) {
+  if (p.small)
+    launch_qgemm_small_output(p, s);
+  else
+    launch_qgemm<true>(p, s);
+}
 
 }  // namespace fdnn

@@ -63,6 +63,7 @@ struct QGemmParams {
   int rows, rows_pad, K, n, n_pad;
   int ldw, lda;           // row strides (bytes) of w and a: K plus the anti-channel-conflict skew
   int frame_tile;         // 32 / 64 / 128 / 160 / 256 / 320, n_pad is a multiple of it
+  int small;              // 1: the small-batch kernel (fdnn_small.hip; frame_tile = 32)
   int debug;              // timing experiments only (FDNN_GEMM_DEBUG): 1 no staging, 2 no MFMA, 4 no LDS reads
   float coef, rcp_coef;
   int fastdiv;
@@ -78,6 +79,12 @@ struct QGemmParams {
   int32_t *tap_acc;       // [n][rows]
   float *tap_logit;       // [n][rows]
 };
+// Small batches (fdnn_small.hip): does this layer (K bytes per row, exact-division epilogue validated) have the
+// small-batch shape, and should a batch of n frames take it?
+bool qgemm_small_ok(int K, int fastdiv);
+bool qgemm_small_pick(int rows_pad, int K, int n, int fastdiv, bool output);
+void launch_qgemm_small_hidden(const QGemmParams &p, hipStream_t s);
+void launch_qgemm_small_output(const QGemmParams &p, hipStream_t s);
 void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s);
 void launch_qgemm_output(const QGemmParams &p, hipStream_t s);
 

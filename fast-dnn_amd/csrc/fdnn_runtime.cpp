@@ -237,12 +237,13 @@ int snapshot_acts(const fdnn_ctx *c, int buf, uint8_t *d_dst, hipStream_t s) {
 
 // GEMM descriptor of one int8 layer over `n` frames starting at activation row
 // `act` (frame tile chosen for this n).
-fdnn::QGemmParams prepare_qlayer(fdnn_ctx *c, const QLayerDesc &d, const int8_t *act, int n, hipStream_t s) {
+fdnn::QGemmParams prepare_qlayer(fdnn_ctx *c, const QLayerDesc &d, const int8_t *act, int n, hipStream_t s, bool output = false) {
   fdnn_model *m = c->m;
   const BlobHeader &h = m->hm.hdr;
   const uint8_t *B = m->d_blob;
   fdnn::QGemmParams g{};
-  g.frame_tile = d.fastdiv_ok ? fdnn::qgemm_frame_tile(d.rows_pad, n) : 128;  // the true-divide kernel has one shape
+  g.small = fdnn::qgemm_small_pick(d.rows_pad, d.cols_pad - fdnn::kRowSkew, n, d.fastdiv_ok, output) ? 1 : 0;
+  g.frame_tile = g.small ? 32 : d.fastdiv_ok ? fdnn::qgemm_frame_tile(d.rows_pad, n) : 128;  // the true-divide kernel has one shape
   g.debug = fdnn::qgemm_debug_flags();
   g.n = n;
   g.n_pad = round_up(n, g.frame_tile);
@@ -342,7 +343,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   if (c->last < 0) return fail(FDNN_E_STATE, "output requested before the hidden layers were computed");
   if (first < 0 || count < 0 || first + count > c->n) return fail(FDNN_E_ARG, "frame range outside the context");
   if (count == 0) return FDNN_OK;
-  fdnn::QGemmParams g = prepare_qlayer(c, d, c->d_act[c->last] + size_t(first) * c->act_ld, count, s);
+  fdnn::QGemmParams g = prepare_qlayer(c, d, c->d_act[c->last] + size_t(first) * c->act_ld, count, s, true);
   g.out = d_out;
   g.partial = c->d_partial;
   g.partial_ld = g.n_pad;
