@@ -239,6 +239,230 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float *base
 }
 #endif
 
+// ---------------------------------------------------------------- small batches: the whole K extent at once
+// One utterance (100 frames) is 88 M MACs -- 3 us of vector work spread over the chip -- and l0_valu_kernel spends
+// 20 us on it: seven k-chunks, each a global -> register -> LDS round trip behind a barrier with one wave per SIMD to
+// hide it.  Here a workgroup owns 32 frames x 32 nodes and loads ALL of its operand rows up front (LDS-DMA, 2 x 32 rows
+// x D floats = 110 KB at D = 432), waits once, applies ApplyShiftAndScale (dnn.cc:175-192: add, then multiply) to its
+// frame rows in LDS, and then runs the four k-mod-4 chains of InputActivations (dnn.cc:219-247) straight through:
+// the same multiplies, adds and combine as l0_valu_kernel, bit for bit.  LDS rows are padded to an ODD number of
+// 16-byte chunks, so the 16 lanes of a ds_read_b128 group (16 different node rows, same k) hit 16 different slots.
+// 256 threads: thread (tx, ty) owns nodes tx, tx + 16 and frames ty, ty + 16.
+template <bool TAP>
+__global__ __launch_bounds__(512) void l0_small_kernel(L0Params p, int sc, unsigned sc_magic, unsigned ch_magic) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem_l0s[];
+  constexpr int TF = 32, TN = 32;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // plain tile order (node tiles fastest): at these sizes the grid is about one workgroup per CU and every XCD
+  // must get its share; the frame rows (a few hundred KB in all) reach every L2 anyway
+  const int node_tiles = (p.H + TN - 1) / TN;
+  const int bx = blockIdx.x % node_tiles, by = blockIdx.x / node_tiles;
+  const int f0 = by * TF, n0 = bx * TN;
+#ifdef FDNN_L0S_CLK
+  long long tc[6];
+  tc[0] = __builtin_readcyclecounter();
+#define L0S_TS(i) tc[i] = __builtin_readcyclecounter()
+#else
+#define L0S_TS(i)
+#endif
+  const int ch = p.D >> 2;                    // 16-byte chunks per operand row
+  const int tile_chunks = 32 * sc;            // per operand tile, pad chunks included
+  const int n_ld = (tile_chunks + 63) >> 6;   // 1-KiB LDS-DMA pieces per operand tile
+  char *xs = smem_l0s;                        // [32][sc] chunks: frames
+  char *ws = xs + n_ld * 1024;                // [32][sc] chunks: nodes
+  char *ss = ws + n_ld * 1024;                // shift [D] | scale [D]
+  uint8_t *lut = reinterpret_cast<uint8_t *>(ss + 2 * ((p.D * 4 + 1023) & ~1023));
+  const int row_bytes = p.D * 4;
+  // rows past the batch / past the layer read as zeros: the descriptors end there
+  const __amdgpu_buffer_rsrc_t rsrc_x = uniform_rsrc(p.x + static_cast<size_t>(f0) * p.D, max(0, min(TF, p.n - f0)) * row_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc_w = uniform_rsrc(p.w + static_cast<size_t>(n0) * p.D, max(0, min(TN, p.H - n0)) * row_bytes);
+  // all eight waves issue (an LDS-DMA piece costs its wave 100-300 cycles of issue time; 110 pieces over four waves
+  // were 9.4 k cycles of a workgroup's 37 k); c / sc by multiplication (magic checked on the host for every c used)
+  for (int i = wave; i < 2 * n_ld; i += 8) {
+    const bool is_w = i >= n_ld;
+    const int c = (is_w ? i - n_ld : i) * 64 + lane;
+    const int row = static_cast<int>(__umulhi(static_cast<unsigned>(c), sc_magic)), col = c - row * sc;
+    const int off = (col < ch && row < 32) ? row * row_bytes + col * 16 : 0x7ffffff0;
+    if (is_w)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, FDNN_LDS_PTR(ws + (i - n_ld) * 1024), 16, off, 0, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, FDNN_LDS_PTR(xs + i * 1024), 16, off, 0, 0, 0);
+  }
+  {  // shift | scale | table: a few more pieces, spread over the waves
+    const int sp = (row_bytes + 1023) >> 10;
+    const __amdgpu_buffer_rsrc_t rsrc_sh = uniform_rsrc(p.shift, row_bytes);
+    const __amdgpu_buffer_rsrc_t rsrc_sc = uniform_rsrc(p.scale, row_bytes);
+    for (int i = 7 - wave; i < 2 * sp; i += 8) {
+      if (i < sp)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_sh, FDNN_LDS_PTR(ss + i * 1024), 16, lane * 16, i * 1024, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_sc, FDNN_LDS_PTR(ss + i * 1024), 16, lane * 16, (i - sp) * 1024, 0, 0);
+    }
+    // (the blob pads the table to kLutExt + 15 bytes; the last 16-byte piece must be inside the descriptor as a whole)
+    const __amdgpu_buffer_rsrc_t rsrc_lut =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(p.lut), 0, (kLutExt + 15) & ~15, 0x00020000);
+    if (wave >= 6) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_lut, FDNN_LDS_PTR(lut + (wave - 6) * 1024), 16, lane * 16, (wave - 6) * 1024, 0, 0);
+  }
+  // this thread's two biases, requested before the wait (first use is the epilogue)
+  const int tx = tid & 15, ty = (tid >> 4) & 15;
+  float bias2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bias2[j] = (tid < 256 && n0 + tx + 16 * j < p.H) ? p.bias[n0 + tx + 16 * j] : 0.0f;
+  L0S_TS(1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  L0S_TS(2);
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  {  // ApplyShiftAndScale on the frame tile, in place (all 512 threads)
+    const char *scs = ss + ((row_bytes + 1023) & ~1023);
+    for (int c = tid; c < 32 * ch; c += 512) {
+      const int row = static_cast<int>(__umulhi(static_cast<unsigned>(c), ch_magic)), col = c - row * ch;
+      v4f *px = reinterpret_cast<v4f *>(xs + (row * sc + col) * 16);
+      const v4f sh = *reinterpret_cast<const v4f *>(ss + col * 16), scl = *reinterpret_cast<const v4f *>(scs + col * 16);
+      v4f v = *px;
+      v.x = (v.x + sh.x) * scl.x;
+      v.y = (v.y + sh.y) * scl.y;
+      v.z = (v.z + sh.z) * scl.z;
+      v.w = (v.w + sh.w) * scl.w;
+      // a frame past the batch stays all-zero (l0_valu_kernel stages zeros there): its outputs are padding rows
+      if (f0 + row < p.n) *px = v;
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (tid >= 256) return;  // the helper waves are done: one wave per SIMD runs the chains
+  L0S_TS(3);
+  float acc[2][2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int l = 0; l < 4; ++l) acc[i][j][l] = 0.0f;
+  const char *xr0 = xs + (ty * sc) * 16, *xr1 = xs + ((ty + 16) * sc) * 16;
+  const char *wr0 = ws + (tx * sc) * 16, *wr1 = ws + ((tx + 16) * sc) * 16;
+  // InputActivations, canonical flavour: four lane partial sums over k mod 4, multiply and add rounded
+  // separately (dnn.cc:233-238); chains (0,1) and (2,3) ride v_pk_mul_f32 / v_pk_add_f32.  Operand reads run
+  // three steps ahead of the arithmetic (one wave per SIMD: nothing else hides the LDS latency); reads past the
+  // last step land in the next row / the next LDS region and are never used.
+  auto rd = [&](v4f (&xv)[2], v4f (&wv)[2], int k4) {
+    xv[0] = *reinterpret_cast<const v4f *>(xr0 + k4 * 16);
+    xv[1] = *reinterpret_cast<const v4f *>(xr1 + k4 * 16);
+    wv[0] = *reinterpret_cast<const v4f *>(wr0 + k4 * 16);
+    wv[1] = *reinterpret_cast<const v4f *>(wr1 + k4 * 16);
+  };
+  auto mac = [&](const v4f (&xv)[2], const v4f (&wv)[2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const v2f x01 = {xv[i].x, xv[i].y}, x23 = {xv[i].z, xv[i].w};
+      v2f pr[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        pr[j][0] = x01 * v2f{wv[j].x, wv[j].y};
+        pr[j][1] = x23 * v2f{wv[j].z, wv[j].w};
+      }
+      asm volatile("" : "+v"(pr[0][0]), "+v"(pr[0][1]), "+v"(pr[1][0]), "+v"(pr[1][1]));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const v2f a01 = v2f{acc[i][j][0], acc[i][j][1]} + pr[j][0], a23 = v2f{acc[i][j][2], acc[i][j][3]} + pr[j][1];
+        acc[i][j][0] = a01.x; acc[i][j][1] = a01.y; acc[i][j][2] = a23.x; acc[i][j][3] = a23.y;
+      }
+    }
+  };
+  v4f x0[2], w0[2], x1[2], w1[2], x2[2], w2[2], x3[2], w3[2];
+  rd(x0, w0, 0);
+  rd(x1, w1, 1);
+  rd(x2, w2, 2);
+  int k4 = 0;
+  for (; k4 + 3 < ch; k4 += 4) {
+    rd(x3, w3, k4 + 3);
+    mac(x0, w0);
+    rd(x0, w0, k4 + 4);
+    mac(x1, w1);
+    rd(x1, w1, k4 + 5);
+    mac(x2, w2);
+    rd(x2, w2, k4 + 6);
+    mac(x3, w3);
+  }
+  if (k4 < ch) mac(x0, w0);
+  if (k4 + 1 < ch) mac(x1, w1);
+  if (k4 + 2 < ch) mac(x2, w2);
+  L0S_TS(4);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = f0 + ty + 16 * i;
+    if (f >= p.n_rows) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int node = n0 + tx + 16 * j;
+      if (node < p.H) {
+        // horizontalSum: (l0+l1)+(l2+l3) (dnn.cc:168-172), then AddBias
+        const float s = (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+        const float lin = s + bias2[j];
+        if (TAP && f < p.n) p.tap_lin[static_cast<size_t>(f) * p.H + node] = lin;
+        p.act_out[static_cast<size_t>(f) * p.act_ld + node] = static_cast<int8_t>(lut[lut_index(lin)]);
+      }
+    }
+  }
+#ifdef FDNN_L0S_CLK
+  L0S_TS(5);
+  if (tid == 0 && (blockIdx.x % 61) == 0)
+    printf("l0s blk %d: issue %lld  land %lld  scale %lld  loop %lld  epi %lld  total %lld\n", blockIdx.x, tc[1] - tc[0], tc[2] - tc[1], tc[3] - tc[2],
+           tc[4] - tc[3], tc[5] - tc[4], tc[5] - tc[0]);
+#endif
+#endif
+}
+
+// LDS the small-batch kernel needs for input width D (0: does not fit, or the division magics are not exact)
+inline unsigned l0_div_magic(int d, int max_c) {
+  const unsigned m = static_cast<unsigned>((0x100000000ull + static_cast<unsigned>(d) - 1) / static_cast<unsigned>(d));
+  for (int c = 0; c <= max_c; ++c)
+    if (static_cast<int>((static_cast<unsigned long long>(c) * m) >> 32) != c / d) return 0;
+  return m;
+}
+struct L0SmallGeom {
+  int sc = 0, lds = 0;
+  unsigned sc_magic = 0, ch_magic = 0;
+};
+inline L0SmallGeom l0_small_geom(int D) {
+  L0SmallGeom g;
+  const int ch = D / 4, sc = ch | 1;
+  const int n_ld = (32 * sc + 63) / 64;
+  const int bytes = 2 * n_ld * 1024 + 2 * ((D * 4 + 1023) & ~1023) + 2048 + 64;
+  if (ch < 2 || bytes > 160 * 1024) return g;  // (ch = 1: the magic 2^32 does not fit 32 bits)
+  g.sc_magic = l0_div_magic(sc, n_ld * 64 + 64);
+  g.ch_magic = l0_div_magic(ch, 32 * ch + 512);
+  if (!g.sc_magic || !g.ch_magic) return g;
+  g.sc = sc;
+  g.lds = bytes;
+  return g;
+}
+
+void launch_l0_small(const L0Params &p, hipStream_t s) {
+  const L0SmallGeom g = l0_small_geom(p.D);
+  auto k = l0_small_kernel<false>;
+  auto kt = l0_small_kernel<true>;
+  static std::atomic<unsigned long long> attr_set{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long dev_bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set.fetch_or(dev_bit, std::memory_order_release);
+  }
+  dim3 grid(static_cast<unsigned>((p.H + 31) / 32) * static_cast<unsigned>((p.n_rows + 31) / 32));
+  if (p.tap_lin)
+    hipLaunchKernelGGL(kt, grid, dim3(512), g.lds, s, p, g.sc, g.sc_magic, g.ch_magic);
+  else
+    hipLaunchKernelGGL(k, grid, dim3(512), g.lds, s, p, g.sc, g.sc_magic, g.ch_magic);
+}
+
 // ---------------------------------------------------------------- VALU, one chain per pass (canonical flavour)
 // The four k-mod-4 chains of an output are independent until (l0+l1)+(l2+l3), so a tile can
 // run them one after the other: pass c walks k = c, c+4, c+8, ... with ONE accumulator per
@@ -915,6 +1139,15 @@ void launch_l0(const L0Params &p, hipStream_t s) {
     // 32-float chunks, 4 x 2 waves (128 x 128 tile).  Measured alternatives at 10 000 frames:
     // 16-float chunks 0.221 ms, 64-float 0.205, 256-thread workgroups (two per CU) 0.205.
     launch_mfma<32, 4>(p, s);
+    return;
+  }
+  // Small batches (canonical flavour): the whole-K kernel, 32 x 32 tiles (100 frames: 20 -> 6 us)
+  static const int small_max = [] {
+    const char *e = std::getenv("FDNN_L0_SMALL_MAX");
+    return e ? std::atoi(e) : 128;  // one round of 32 x 32 tiles on a 2048-node layer; beyond, the (16 | 32) x 64 tiles are as fast
+  }();
+  if (!p.fma && p.kernel == 0 && p.n_rows <= small_max && l0_small_geom(p.D).lds > 0) {
+    launch_l0_small(p, s);
     return;
   }
   // Three bit-identical candidates, chosen by modelled time (432 -> 2048 layer, tools/l0_kind_sweep.py; all three

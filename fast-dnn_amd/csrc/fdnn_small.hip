@@ -63,6 +63,13 @@ __global__ __launch_bounds__(kSmThreads, 2) void qgemm_small_kernel(QGemmParams 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef FDNN_SM_CLK
+  long long tc[8];
+  tc[0] = __builtin_readcyclecounter();
+#define SM_TS(i) tc[i] = __builtin_readcyclecounter()
+#else
+#define SM_TS(i)
+#endif
 
   // Workgroup b runs on XCD b % 8 (a locality hint, nothing depends on it): the frame groups of one node tile
   // go to one XCD, so a weight tile is pulled into one L2.
@@ -137,26 +144,22 @@ __global__ __launch_bounds__(kSmThreads, 2) void qgemm_small_kernel(QGemmParams 
     for (int s = 0; s < 8; ++s) wf[half][s] = *reinterpret_cast<const v4i *>(src + sm_pos(frow, 2 * s + fch));
   };
 
-  // ---- prologue: W through the (not yet needed) activation buffers into registers, first activation tiles behind it
+  SM_TS(1);
+  // ---- prologue: W through the (not yet needed) second activation buffer into registers, the first activation tile
+  // beside it.  64-node shape: the second half of W follows through the same buffer while the first half's MFMAs run
+  // (see the first pass of the tile loop) -- both halves at once would need both buffers, and the activation tile
+  // could only be requested once they had landed.
   if (slice_live) {
     load_w(0, abuf0 + kSmABuf);
+    load_a(t_begin, abuf0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // older loads complete first: table / bias / 128 sum(w) + W half 0 landed
+    read_w(0, abuf0 + kSmABuf);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     if (NTM == 1) {
-      load_a(t_begin, abuf0);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // older loads complete first: table/bias + W landed
-      read_w(0, abuf0 + kSmABuf);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
       if (t_begin + 1 < t_end) load_a(t_begin + 1, abuf0 + kSmABuf);
     } else {
-      load_w(1, abuf0);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      read_w(0, abuf0 + kSmABuf);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      read_w(1, abuf0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      load_a(t_begin, abuf0);
-      if (t_begin + 1 < t_end) load_a(t_begin + 1, abuf0 + kSmABuf);
+      load_w(1, abuf0 + kSmABuf);
     }
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // a wave without a slice may still have issued table / bias loads
@@ -167,26 +170,36 @@ __global__ __launch_bounds__(kSmThreads, 2) void qgemm_small_kernel(QGemmParams 
   }
 
   // pmaddubsw saturation entries of this tile's 64-node group whose pair lies in this wave's K slice: sorted by k
-  // inside the group, so they are one contiguous range (found once; walked per frame tile with scalar loads)
+  // inside the group, so they are one contiguous run.  Its start is found from an interpolated guess (k is spread
+  // evenly: a walk from the group's first entry cost the last wave ~60 dependent scalar loads), and the run's first
+  // kFixPre entries are fetched into SGPRs here, under the operand loads' flight time.
   typedef const __attribute__((address_space(4))) uint64_t *FixPtr;
   const FixPtr ent_c = (FixPtr)(uintptr_t)p.fix_ent;  // {u16 k, s8 w0, s8 w1, s32 node}
-  int fix_b = 0, fix_e = 0;
+  constexpr int kFixPre = 8;
+  int fix_b = 0, fix_end = 0;
+  uint64_t fix_pre[kFixPre];
+#pragma unroll
+  for (int i = 0; i < kFixPre; ++i) fix_pre[i] = 0xffffull;  // k = 65535: past every slice
   if (p.fix_ent && slice_live) {
     const int grp = m0 >> 6;
     typedef const __attribute__((address_space(4))) int *GrpPtr;
     const GrpPtr grp_c = (GrpPtr)(uintptr_t)p.fix_grp;  // scalar loads: no vector-memory wait beside the LDS-DMA queue
-    int e = grp_c[grp];
-    const int end = grp_c[grp + 1];
-    while (e < end && static_cast<int>(ent_c[e] & 0xffff) < k0) ++e;
+    const int g_begin = grp_c[grp];
+    fix_end = grp_c[grp + 1];
+    int e = g_begin + static_cast<int>(static_cast<long long>(fix_end - g_begin) * k0 / p.K);
+    while (e > g_begin && static_cast<int>(ent_c[e - 1] & 0xffff) >= k0) --e;
+    while (e < fix_end && static_cast<int>(ent_c[e] & 0xffff) < k0) ++e;
     fix_b = e;
-    while (e < end && static_cast<int>(ent_c[e] & 0xffff) < k0 + kSmSlice) ++e;
-    fix_e = e;
+#pragma unroll
+    for (int i = 0; i < kFixPre; ++i)
+      if (fix_b + i < fix_end) fix_pre[i] = ent_c[fix_b + i];
   }
 
   const uint8_t *lut = reinterpret_cast<const uint8_t *>(aux);
   const float *bias_s = reinterpret_cast<const float *>(smem + kSmBiasOff);
   float *e_s = reinterpret_cast<float *>(smem + kSmEOff);  // OUTPUT: e values [frame][64 nodes] for the ordered partial sums
 
+  SM_TS(2);
   for (int t = t_begin; t < t_end; ++t) {
     const int cur = (t - t_begin) & 1;
     char *at = abuf0 + cur * kSmABuf;
@@ -198,22 +211,41 @@ __global__ __launch_bounds__(kSmThreads, 2) void qgemm_small_kernel(QGemmParams 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[h][r] = 0;
     if (slice_live) {
-      if (t + 1 < t_end)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile t landed, tile t+1 (8 loads) may still fly
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       v4i b[8];
+      auto read_b = [&]() {
 #pragma unroll
-      for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const v4i *>(at + sm_pos(frow, 2 * s + fch));
+        for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const v4i *>(at + sm_pos(frow, 2 * s + fch));
+      };
+      if (NTM == 2 && t == t_begin) {
+        // first pass of the 64-node shape: in flight are this tile (8 loads) and W half 1 (8 loads, younger)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (t == t_begin) SM_TS(3);
+        read_b();
 #pragma unroll
-      for (int s = 0; s < 8; ++s)
+        for (int s = 0; s < 8; ++s) acc[0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[0][s], b[s], acc[0], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        read_w(NTM - 1, abuf0 + kSmABuf);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < t_end) load_a(t + 1, abuf0 + kSmABuf);
 #pragma unroll
-        for (int h = 0; h < NTM; ++h) acc[h] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[h][s], b[s], acc[h], 0, 0, 0);
+        for (int s = 0; s < 8; ++s) acc[NTM - 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[NTM - 1][s], b[s], acc[NTM - 1], 0, 0, 0);
+      } else {
+        if (t + 1 < t_end)
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // tile t landed, tile t+1 (8 loads) may still fly
+        else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == t_begin) SM_TS(3);
+        read_b();
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+          for (int h = 0; h < NTM; ++h) acc[h] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[h][s], b[s], acc[h], 0, 0, 0);
+      }
       // saturating pairs (rare): the reference clamps a[2j]*w[2j] + a[2j+1]*w[2j+1] to int16 (dnn.cc:337-340)
-      for (int e = fix_b; e < fix_e; ++e) {
-        const uint64_t raw = ent_c[e];
+      auto fix_one = [&](uint64_t raw) {
         const int node = static_cast<int>(raw >> 32) - m0;
-        if (node < 0 || node >= NT) continue;  // NTM == 1: the other half of the 64-node group
+        if (node < 0 || node >= NT) return;  // NTM == 1: the other half of the 64-node group
         const int kl = static_cast<int>(raw & 0xffff) - k0;  // even, 0..254
         const int w0 = static_cast<int8_t>(raw >> 16), w1 = static_cast<int8_t>(raw >> 24);
         const uint32_t pair = *reinterpret_cast<const uint16_t *>(at + sm_pos(frow, kl >> 4) + (kl & 15));
@@ -228,7 +260,21 @@ __global__ __launch_bounds__(kSmThreads, 2) void qgemm_small_kernel(QGemmParams 
           for (int i = 0; i < 16 * NTM; ++i)
             if (idx == i) acc[i >> 4][i & 15] += c;
         }
+      };
+      bool more = true;
+#pragma unroll
+      for (int i = 0; i < kFixPre; ++i) {
+        if (more && static_cast<int>(fix_pre[i] & 0xffff) < k0 + kSmSlice)
+          fix_one(fix_pre[i]);
+        else
+          more = false;
       }
+      if (more)  // a run longer than the prefetched entries (nets with weights near +-127 everywhere)
+        for (int e = fix_b + kFixPre; e < fix_end; ++e) {
+          const uint64_t raw = ent_c[e];
+          if (static_cast<int>(raw & 0xffff) >= k0 + kSmSlice) break;
+          fix_one(raw);
+        }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     // partial tile -> this wave's own (just consumed) 8 KiB of the activation buffer: [half][frame][32 nodes] int32,
@@ -240,9 +286,11 @@ __global__ __launch_bounds__(kSmThreads, 2) void qgemm_small_kernel(QGemmParams 
       for (int g = 0; g < 4; ++g)
         *reinterpret_cast<v4i *>(reinterpret_cast<char *>(part) + h * 4096 + frow * 128 + ((((2 * g + fch) ^ frow) & 7) << 4)) =
             v4i{acc[h][g * 4], acc[h][g * 4 + 1], acc[h][g * 4 + 2], acc[h][g * 4 + 3]};
+    if (t == t_begin) SM_TS(4);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (t == t_begin) SM_TS(5);
 
     // ---- reduce + epilogue: thread -> (frame f, node quad Q); NTM == 1: threads 0..255, NTM == 2: all 512
     const int f = (tid >> 3) & 31, q = tid & 7, h = tid >> 8;  // quad Q = 8h + q: nodes m0 + 32h + 4q ..+3
@@ -309,6 +357,7 @@ __global__ __launch_bounds__(kSmThreads, 2) void qgemm_small_kernel(QGemmParams 
         *reinterpret_cast<v4f_t *>(e_s + f * 64 + 32 * h + 4 * q) = v4f_t{e4[0], e4[1], e4[2], e4[3]};
       }
     }
+    if (t == t_begin) SM_TS(6);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // every partial is read: the buffer may be refilled; OUTPUT: e_s is complete
     asm volatile("" ::: "memory");
@@ -333,6 +382,12 @@ __global__ __launch_bounds__(kSmThreads, 2) void qgemm_small_kernel(QGemmParams 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
+#ifdef FDNN_SM_CLK
+  SM_TS(7);
+  if ((tid == 0 || tid == 448) && (blockIdx.x % 97) == 0)
+    printf("%s blk %d w%d: setup %lld  prologue %lld  wait-A %lld  mfma+part %lld  barrier %lld  epi %lld  rest %lld  total %lld\n", OUTPUT ? "OUT" : "hid",
+           blockIdx.x, wave, tc[1] - tc[0], tc[2] - tc[1], tc[3] - tc[2], tc[4] - tc[3], tc[5] - tc[4], tc[6] - tc[5], tc[7] - tc[6], tc[7] - tc[0]);
+#endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
