@@ -92,6 +92,7 @@ SIGNATURES = {
     "fdnn_model_blob_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "fdnn_model_export_blob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fdnn_model_import_blob": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "fdnn_debug_production_acc_out": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, _c_i8p, _c_i32p, _c_f32p]),
     "fdnn_debug_forward_taps": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_i8p, _c_f32p, _c_u8p, _c_i32p, _c_i32p, _c_f32p, _c_f32p]),
     "fdnn_debug_layer0": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_u8p, C.POINTER(C.c_ulonglong)]),
     "fdnn_profile_begin": (C.c_int, [C.c_void_p]),
@@ -400,7 +401,7 @@ class QuantizedDnn:
         _check(lib().fdnn_model_set_l0_fma(self.nativeDnnHandle, int(on)))
 
     def setInputLayerKernel(self, kind: int) -> None:
-        """0 = chosen by batch size, 1 = chain-pass kernel, 2 = 64 x 64-tile kernel (same bits)."""
+        """0 = chosen by batch size, 1 = chain-pass kernel, 2 = 64 x 64-tile kernel, 3 = screened path where available (same bits)."""
         _check(lib().fdnn_debug_set_l0_kernel(self.nativeDnnHandle, int(kind)))
 
     # -- dense path ---------------------------------------------------------
@@ -457,6 +458,22 @@ class QuantizedDnn:
         return out, int(rec.value)
 
     # -- parity taps ----------------------------------------------------------
+    def productionOutputAcc(self, input, stride: int, masks=None, probs: bool = False):
+        """int32 accumulators of the output layer's PRODUCTION kernel instance for every stride-th frame
+        ([ceil(n/stride)][O]); with probs=True also the call's probabilities."""
+        x = _f32(input)
+        n, O = x.shape[0], self.outputDimension()
+        acc = np.empty(((n + stride - 1) // stride, O), dtype=np.int32)
+        pr = np.empty((n, O), dtype=np.float32) if probs else None
+        m = None
+        if masks is not None:
+            m = np.ascontiguousarray(masks, dtype=np.int8)
+            assert m.shape == (n, O)
+        _check(lib().fdnn_debug_production_acc_out(
+            self.nativeDnnHandle, x.ctypes.data_as(_c_f32p), n, stride, m.ctypes.data_as(_c_i8p) if m is not None else None,
+            acc.ctypes.data_as(_c_i32p), pr.ctypes.data_as(_c_f32p) if pr is not None else None))
+        return (acc, pr) if probs else acc
+
     def forwardTaps(self, input, masks=None) -> dict:
         x = _f32(input)
         n, H, O = x.shape[0], self.hiddenDimension(), self.outputDimension()

@@ -497,6 +497,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     return;
   }
 #endif
+  if (OUTPUT && p.acc_probe != nullptr) {  // parity tests: the raw accumulators of every probe_stride-th frame (uniform branch)
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni) {
+      const int f = fw0 + 32 * ni + frow;
+      if (f < p.n && f % p.probe_stride == 0) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int node = m0 + 64 * wm + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (node < p.rows) p.acc_probe[static_cast<size_t>(f / p.probe_stride) * p.rows + node] = acc[mi][ni][r];
+          }
+      }
+    }
+  }
   if (OUTPUT) {
     // CalculateOutput / LazyOutputActivations: z = sum/coef + bias (masked-out nodes keep
     // z = 0, dnn.cc:366-369), e = exp(z) (SoftMax::apply first loop, dnn.cc:536-540).
@@ -518,7 +533,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     uint8_t *mtile = reinterpret_cast<uint8_t *>(smem + 8192 + NW * (32 * kOS * 4)) + wave * (32 * kMS);
     static_assert(8192 + NW * (32 * kOS * 4) + NW * (32 * kMS) <= Cfg::FIX_OFF, "mask tiles must not reach the table/biases");
     const bool wt_rows = (p.rows & 31) == 0;
-    const bool mask_staged = MASKED || (!PLAIN && p.mask != nullptr && vec4);
+    // The production lazy instances (MASKED) read the mask as BITS: one 64-bit word per frame row covers this wave's 64
+    // nodes (launch_mask_pack has turned the caller's 80 MB of bytes into 10 MB of bits at HBM speed).  Eight dwords per
+    // lane, an LDS round trip per piece and 30 spilled registers went with the byte version: 0.215 -> 0.18x ms.
+    const bool mask_staged = !PLAIN && p.mask != nullptr && vec4;
+    auto bits_fetch = [&](int ni) -> uint64_t {
+      const int ff = fw0 + 32 * ni + frow, grp = ncol0 >> 6;
+      return (ff < p.n && grp < p.mask_wpr) ? p.mask_bits[static_cast<size_t>(ff) * p.mask_wpr + grp] : 0ull;
+    };
+    // all NF words up front, before the first result store: vmcnt counts stores too, so a load issued between them would
+    // wait for every earlier store's acknowledgement (one such wait per frame block: 192 vs 180 us)
+    uint64_t mwords[NF];
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni) mwords[ni] = MASKED ? bits_fetch(ni) : 0ull;
     uint32_t mreg[8];  // the next piece is fetched while the current one is being used
     auto mask_fetch = [&](int ni) {
 #pragma unroll
@@ -544,6 +571,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
       for (int ni = 0; ni < NF; ++ni) {
         const int f = fw0 + 32 * ni + frow;
         const bool live = f < p.n;
+        const uint64_t mword = mwords[ni];
         if ((MASKED || !PLAIN) && mask_staged) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
@@ -560,7 +588,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
             const float4 b4 = *reinterpret_cast<const float4 *>(bias_s + (nb - m0));
             const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
             uint32_t mbits = 0x01010101u;
-            if ((MASKED || !PLAIN) && mask_staged) {
+            if (MASKED) {  // four bits -> four bytes (bit i to byte i; the products land on distinct bits: no carries)
+              const uint32_t nib = static_cast<uint32_t>(mword >> (32 * mi + 8 * g + 4 * half)) & 0xfu;
+              mbits = (nib * 0x00204081u) & 0x01010101u;
+            } else if ((MASKED || !PLAIN) && mask_staged) {
               mbits = *reinterpret_cast<const uint32_t *>(mtile + frow * kMS + (nb - ncol0));
             } else if (!PLAIN && p.mask && live && nb < p.rows) {
               const int8_t *mp = p.mask + static_cast<size_t>(f) * p.rows + nb;
@@ -897,15 +928,18 @@ int qgemm_frame_tile(int rows_pad, int n) {
   return best;
 }
 
-// Batches up to this many frames take the small-batch kernel (fdnn_small.hip) where the layer allows it.
+// Batches up to this many frames take the small-batch kernel (fdnn_small.hip) where the layer allows it.  Measured
+// crossovers on the 2048-wide layers (tools/batch_sweep.py, FDNN_SMALL_MAX=0 against the default): six hidden layers
+// 60 vs 88 us at 256 frames, 80 vs 90 at 512, 104 vs 95 at 700; the 8000-node output layer 16.5 vs 24.6 at 256,
+// 25.8 vs 26.3 at 512, 47 vs 30 at 1000 (a workgroup of the small kernel walks its frame tiles one after the other).
 bool qgemm_small_pick(int rows_pad, int K, int n, int fastdiv, bool output) {
   static const int small_max = [] {
     const char *e = std::getenv("FDNN_SMALL_MAX");
-    return e ? std::atoi(e) : 1024;
+    return e ? std::atoi(e) : -1;
   }();
   (void)rows_pad;
-  (void)output;
-  return n <= small_max && qgemm_small_ok(K, fastdiv);
+  const int lim = small_max >= 0 ? small_max : output ? 512 : 640;
+  return n <= lim && qgemm_small_ok(K, fastdiv);
 }
 
 void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s) {

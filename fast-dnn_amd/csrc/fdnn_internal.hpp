@@ -81,6 +81,7 @@ struct fdnn_ctx {
   float *d_out = nullptr;         // [n][O]
   float *d_partial = nullptr;     // [rows_pad/64][n_pad]
   int8_t *d_mask = nullptr;       // [n][O]
+  uint64_t *d_mask_bits = nullptr;  // [n][ceil(O/64)] the batched lazy call's mask as bits (launch_mask_pack)
   int last = -1;                  // d_act index holding the last hidden layer, -1 = not computed
   bool pooled = false;
   bool l0_chain_only = false;     // scoring loop, large batches: the soft-max scale of the previous batch runs under this
@@ -103,6 +104,8 @@ struct Taps {
   int32_t *acc_hid = nullptr;   // device [n_hidden-1][n][H]
   int32_t *acc_out = nullptr;   // device [n][O]
   float *logits = nullptr;      // device [n][O]
+  int32_t *acc_probe = nullptr; // device [ceil(n / probe_stride)][O]: accumulators of the PRODUCTION output instance (no tap kernels)
+  int probe_stride = 1;
 };
 
 int make_ctx(fdnn_model *m, int n, fdnn_ctx **out);

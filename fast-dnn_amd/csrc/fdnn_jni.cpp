@@ -9,6 +9,7 @@
 //     argument errors) with fdnn_last_error() instead of crashing / exit(3)
 //     (float_dnn.cc:171, :185-188).
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -67,7 +68,16 @@ struct Scratch {
     return p;
   }
 };
-constexpr size_t kScratchMax = size_t(256) << 20;  // bytes a thread keeps between calls
+// Bytes a calling thread keeps between calls (a 100-frame utterance of an 8000-output net is 3.2 MB; 64 Java threads
+// that each once scored a 256 MB batch would otherwise pin 16 GB for their lifetime).  FDNN_JNI_KEEP_MB overrides.
+size_t scratch_keep_bytes() {
+  static const size_t v = [] {
+    const char *e = std::getenv("FDNN_JNI_KEEP_MB");
+    const long mb = e ? std::atol(e) : 32;
+    return static_cast<size_t>(mb < 0 ? 0 : mb) << 20;
+  }();
+  return v;
+}
 thread_local Scratch t_scratch;
 
 jfloatArray to_java(JNIEnv *env, const float *data, size_t len) {
@@ -103,8 +113,12 @@ jint Java_suskun_nn_QuantizedDnn_outputDimension(JNIEnv *, jobject, jlong handle
 jfloatArray Java_suskun_nn_QuantizedDnn_calculate(JNIEnv *env, jobject, jlong handle, jfloatArray flat, jint n, jint dim,
                                                   jint batch) {
   fdnn_model *m = reinterpret_cast<fdnn_model *>(handle);
+  const size_t len = static_cast<size_t>(n < 0 ? 0 : n) * static_cast<size_t>(fdnn_model_output_dim(m));
+  if (n < 0 || len > static_cast<size_t>(INT32_MAX)) {  // a Java float[] holds at most 2^31 - 1 elements (jsize is a 32-bit int)
+    throw_status(env, FDNN_E_ARG, "frames x output nodes does not fit a Java float[] (2^31 - 1 elements): score the batch in pieces");
+    return nullptr;
+  }
   jfloat *elements = slot<GetFloatArrayElementsFn>(env, FDNN_JNI_GetFloatArrayElements)(env, flat, nullptr);
-  const size_t len = static_cast<size_t>(n) * static_cast<size_t>(fdnn_model_output_dim(m));
   float *out = t_scratch.get(len);
   int rc = out ? fdnn_calculate(m, elements, n, dim, batch, out) : FDNN_E_NOMEM;
   slot<ReleaseFloatArrayElementsFn>(env, FDNN_JNI_ReleaseFloatArrayElements)(env, flat, elements, FDNN_JNI_ABORT);
@@ -113,7 +127,7 @@ jfloatArray Java_suskun_nn_QuantizedDnn_calculate(JNIEnv *env, jobject, jlong ha
     throw_status(env, rc, out ? nullptr : "out of host memory for the result block");
   else
     result = to_java(env, out, len);
-  if (len * sizeof(float) > kScratchMax) t_scratch.release();
+  if (len * sizeof(float) > scratch_keep_bytes()) t_scratch.release();
   return result;
 }
 

@@ -194,7 +194,68 @@ __global__ __launch_bounds__(256) void xor80_kernel(const int8_t *in, uint8_t *o
   if (i < count) out[i] = static_cast<uint8_t>(in[i]) ^ 0x80;
 }
 
+// ---------------------------------------------------------------- lazy masks: bytes -> bits
+// One 64-bit word per 64 nodes.  Lane l of a quad takes 16 mask bytes (one dwordx4: a wave reads 1 KiB contiguous),
+// turns them into 16 bits, and the quad's first lane collects the four pieces.
+__device__ __forceinline__ uint32_t nonzero_bytes_to_bits(uint32_t x) {
+  const uint32_t m = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;  // bit 7 of every non-zero byte
+  return (((m >> 7) * 0x01020408u) >> 24) & 0xfu;                            // ... gathered into bits 0..3
+}
+__global__ __launch_bounds__(256) void mask_pack_kernel(const int8_t *mask, uint64_t *bits, int n, int rows, int wpr) {
+  const long long total = static_cast<long long>(n) * wpr * 4;  // 16-byte pieces, rows padded to whole words
+  const long long stride = static_cast<long long>(gridDim.x) * 256;
+  constexpr int U = 4;  // pieces in flight per thread: the pass is one long HBM read
+  for (long long i0 = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i0 < total; i0 += U * stride) {
+    uint4 v[U];
+    int fr[U], pc[U];
+    bool fast[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long i = i0 + u * stride;
+      v[u] = make_uint4(0, 0, 0, 0);
+      fr[u] = pc[u] = 0;
+      fast[u] = false;
+      if (i < total) {
+        fr[u] = static_cast<int>(i / (wpr * 4));
+        pc[u] = static_cast<int>(i - static_cast<long long>(fr[u]) * (wpr * 4));
+        const int8_t *src = mask + static_cast<size_t>(fr[u]) * rows + pc[u] * 16;
+        fast[u] = pc[u] * 16 + 16 <= rows && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+        if (fast[u]) {
+          const v4i t = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(src));
+          v[u] = make_uint4(static_cast<uint32_t>(t.x), static_cast<uint32_t>(t.y), static_cast<uint32_t>(t.z), static_cast<uint32_t>(t.w));
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long i = i0 + u * stride;
+      uint32_t b = 0;
+      if (fast[u]) {
+        b = nonzero_bytes_to_bits(v[u].x) | nonzero_bytes_to_bits(v[u].y) << 4 | nonzero_bytes_to_bits(v[u].z) << 8 |
+            nonzero_bytes_to_bits(v[u].w) << 12;
+      } else if (i < total) {
+        const int col = pc[u] * 16;
+        const int8_t *src = mask + static_cast<size_t>(fr[u]) * rows + col;
+        for (int q = 0; q < 16; ++q)
+          if (col + q < rows && src[q] != 0) b |= 1u << q;
+      }
+      // the quad's pieces -> one word (the four lanes of a quad are in range together: total and stride are multiples of 4)
+      const uint32_t b1 = __shfl_down(b, 1), b2 = __shfl_down(b, 2), b3 = __shfl_down(b, 3);
+      if (i < total && (pc[u] & 3) == 0)
+        bits[static_cast<size_t>(fr[u]) * wpr + (pc[u] >> 2)] =
+            static_cast<uint64_t>(b | b1 << 16) | static_cast<uint64_t>(b2 | b3 << 16) << 32;
+    }
+  }
+}
+
 }  // namespace
+
+void launch_mask_pack(const int8_t *mask, uint64_t *bits, int n, int rows, hipStream_t s) {
+  const int wpr = (rows + 63) / 64;
+  const long long total = static_cast<long long>(n) * wpr * 4;
+  const int blocks = static_cast<int>(std::min<long long>((total + 255) / 256, 256 * 16));
+  if (blocks > 0) hipLaunchKernelGGL(mask_pack_kernel, dim3(blocks), dim3(256), 0, s, mask, bits, n, rows, wpr);
+}
 
 void launch_normalize(float *out, float *dst, const float *partial, int n, int partial_ld, int rows, int n_partial, hipStream_t s,
                       bool background) {

@@ -75,6 +75,12 @@ struct QGemmParams {
   float *partial;         // [rows_pad/kPartialNodes][partial_ld]
   int partial_ld;
   const int8_t *mask;     // [n][rows] or null (lazy contract)
+  const uint64_t *mask_bits;  // [n][mask_wpr] the same mask, one bit per node (launch_mask_pack), or null: the large-batch
+  int mask_wpr;               // production instances read one 64-bit word per frame row and 64-node group instead of 64 bytes
+  // accumulator probe of the PRODUCTION output instances (parity tests only; null otherwise): the int32 accumulators of
+  // every probe_stride-th frame, [ceil(n / probe_stride)][rows] -- a wave-uniform branch in front of the epilogue
+  int32_t *acc_probe;
+  int probe_stride;
   // taps (null in production)
   int32_t *tap_acc;       // [n][rows]
   float *tap_logit;       // [n][rows]
@@ -103,6 +109,11 @@ struct LazyFrameParams {
   int fastdiv;
 };
 void launch_lazy_frame(const LazyFrameParams &p, hipStream_t s);
+
+// bits[f][w] bit b = mask[f][64 w + b] != 0  (words per row = ceil(rows / 64); bits past the row are zero).  The lazy
+// contract's byte masks (80 MB for 10 000 frames x 8000 nodes) are read once here, at HBM speed, instead of inside the
+// output GEMM's epilogue.
+void launch_mask_pack(const int8_t *mask, uint64_t *bits, int n, int rows, hipStream_t s);
 
 // dst[f][:] = out[f][:] / sum_t partial[t][f]   (dst == out: in place; dst may be host-mapped)
 // background: a small fixed grid walking the rows (server loop: runs under the next batch's layer 0)

@@ -741,7 +741,8 @@ struct L0MfmaCfg {
 //   steps: inside a window |s_j| <= |s_start| + S_window, so  sum_j |s_j| <= W A + W S  with  A = sum over windows and chains of
 //   |s_start|  (accumulated in registers; the kernel keeps one A per frame row and pair of node columns: an upper bound of
 //   each), and |s'_j| <= |s_j| + 218 u S  (the classical gamma_n bound).  Hence
-//     |lin_fused - lin_unfused| <= E = 1.0002 u (2W A + (2W + 1) S + 8 (F + |bias|)),
+//     |lin_fused - lin_unfused| <= E = 1.0002 u (2W A + (2W + 1 + c2) S + 8 (F + |bias|)),   c2 = (D^2/2 + 2D) u  [the
+//   second-order term: sum_j u |s'_j - s_j| over the D steps of the four chains],
 //   the last term for the three adds of (l0+l1)+(l2+l3) and the bias add (the same operations on both sides, each can
 //   widen the gap by one rounding of a value <= F + |bias|, F = sum of the four final |chain values|), and S <=
 //   ||x||_2 ||w||_2 (Cauchy-Schwarz, both norms rounded up).  |fl(100 lin) - fl(100 lin')| <= D = 100.001 E + 4 u |fl(100 lin)|;
@@ -919,6 +920,10 @@ __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
     const float bias = node < p.H ? p.bias[node] : 0.0f;
     const float wn_bound = (SCREEN && node < p.H) ? p.wnorm[node] : 0.0f;
     constexpr float kScreenE = 1.0002f * 5.9604645e-8f, kScreenT = 4.0f * 5.9604645e-8f;  // 1.0002 u (covers 1/(1-u) and float evaluation of E), 4 u
+    // second order in u: the unfused chain's own partial sums differ from the sampled (fused) ones, |s'_j - s_j| <= (D/2 + 2) u S,
+    // which over the D steps of the four chains adds (D^2 / 2 + 2 D) u^2 S -- 0.006 u S at D = 432, but growing with D^2
+    // (it used to ride on the 1.0002's slack, which only holds up to D ~ 470)
+    const float c2 = 1.001f * (0.5f * static_cast<float>(p.D) * static_cast<float>(p.D) + 2.0f * static_cast<float>(p.D)) * 5.9604645e-8f;
     uint8_t act[16];  // table gathers first, tile writes after: the two alias in LDS as far as the compiler knows
     uint8_t nb0[16], nb1[16];
 #pragma unroll
@@ -945,7 +950,7 @@ __global__ __launch_bounds__(128 * WFR, 2) void l0_mfma_kernel(L0Params p) {
         const float xn = f0 + row < p.n ? xn_s[row] : 0.0f;
         const float F = (fabsf(acc[s][0][r]) + fabsf(acc[s][0][16 + r])) + (fabsf(acc[s][1][r]) + fabsf(acc[s][1][16 + r]));
         constexpr float kW = 2.0f * (BK / 4) * kScreenEvery;  // 2 x steps per window: both chains' partial sums
-        const float E = fmaf(kW, absacc[SCREEN ? r : 0], fmaf((kW + 1.0f) * xn, wn_bound, 8.0f * (F + fabsf(bias)))) * kScreenE;
+        const float E = fmaf(kW, absacc[SCREEN ? r : 0], fmaf((kW + 1.0f + c2) * xn, wn_bound, 8.0f * (F + fabsf(bias)))) * kScreenE;
         const float D = fmaf(100.001f, E, fabsf(t) * kScreenT) + 1e-30f;
         const float fr = fabsf((t - floorf(t)) - 0.5f);  // distance to the nearest half-integer (exact below 2^23)
         const bool near = !(fr > D) && !(fabsf(t) - D >= 641.0f);     // written so that a NaN flags
@@ -1167,9 +1172,10 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   const double tile64_us = p.n_rows <= 320    ? 23.0 * work
                            : p.n_rows <= 1200 ? (17.0 + 0.032 * p.n_rows) * work
                                               : 20.0 + 0.0355 * work * (p.H / 2048.0) * p.n_rows;
-  const bool can_screen = !p.fma && !no_screen && p.kernel == 0 && !p.tap_lin && p.wnorm && p.scr_count && p.scr_list && p.n >= 2048;
+  const bool can_screen = !p.fma && !no_screen && (p.kernel == 0 || p.kernel == 3) && !p.tap_lin && p.wnorm && p.scr_count && p.scr_list && p.n >= 2048 &&
+                          p.D <= 8192;  // l0_fix_kernel stages one operand row pair in 8 D bytes of dynamic LDS (64 KB without an attribute)
   const bool can_chain = !p.fma && p.xt && p.wt && p.kernel != 2 && !(classic && p.kernel == 0);
-  if (can_screen && screened_us < (can_chain ? chain_us : tile64_us) && screened_us < tile64_us) {
+  if (can_screen && (p.kernel == 3 || (screened_us < (can_chain ? chain_us : tile64_us) && screened_us < tile64_us))) {
     launch_screened(p, s);
     return;
   }

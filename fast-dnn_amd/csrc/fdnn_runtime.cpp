@@ -139,6 +139,7 @@ void destroy_ctx(fdnn_ctx *c) {
   hipFree(c->d_out);
   hipFree(c->d_partial);
   hipFree(c->d_mask);
+  hipFree(c->d_mask_bits);
   if (c->h_mask_pin) hipHostFree(c->h_mask_pin);
   if (c->h_out_pin) hipHostFree(c->h_out_pin);
   if (c->done) hipEventDestroy(c->done);
@@ -183,6 +184,7 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
   alloc(reinterpret_cast<void **>(&c->d_out), sizeof(float) * np * h.out_dim);
   alloc(reinterpret_cast<void **>(&c->d_partial), sizeof(float) * npt * (max_rows_pad / fdnn::kPartialNodes));
   alloc(reinterpret_cast<void **>(&c->d_mask), np * h.out_dim);
+  alloc(reinterpret_cast<void **>(&c->d_mask_bits), sizeof(uint64_t) * np * size_t((h.out_dim + 63) / 64));
   if (e == hipSuccess)  // at least one padded row: the one-frame kernel reads the mask in 16-byte pieces up to rows_pad
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mask_pin), std::max(size_t(kPinFrames) * h.out_dim, size_t(max_rows_pad)), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_mask_pin), c->h_mask_pin, 0);
@@ -348,8 +350,17 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   g.partial = c->d_partial;
   g.partial_ld = g.n_pad;
   g.mask = d_masks;
+  if (d_masks && !g.small && !(taps && taps->acc_out)) {
+    // large-batch production instances: the mask travels as bits (one pass over the caller's bytes at HBM speed)
+    ProfScope ps(m, s, FDNN_PROF_OUTPUT);
+    fdnn::launch_mask_pack(d_masks, c->d_mask_bits, count, d.rows, s);
+    g.mask_bits = c->d_mask_bits;
+    g.mask_wpr = (d.rows + 63) / 64;
+  }
   g.tap_acc = taps ? taps->acc_out : nullptr;
   g.tap_logit = taps ? taps->logits : nullptr;
+  g.acc_probe = taps ? taps->acc_probe : nullptr;
+  g.probe_stride = taps ? std::max(1, taps->probe_stride) : 1;
   {
     ProfScope ps(m, s, FDNN_PROF_OUTPUT);
     fdnn::launch_qgemm_output(g, s);
@@ -655,7 +666,7 @@ int fdnn_model_set_l0_fma(fdnn_model *m, int on) {
 
 int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind) {
   if (!m) return fail(FDNN_E_ARG, "null model");
-  if (kind < 0 || kind > 2) return fail(FDNN_E_ARG, "layer-0 kernel kind must be 0, 1 or 2");
+  if (kind < 0 || kind > 3) return fail(FDNN_E_ARG, "layer-0 kernel kind must be 0, 1, 2 or 3");
   m->l0_kernel = kind;
   return FDNN_OK;
 }
@@ -894,6 +905,35 @@ int fdnn_debug_forward_taps(fdnn_model *m, const float *x, int n, const int8_t *
   fdnn_ctx_free(c);
   if (rc) return rc;
   if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("taps: ") + hipGetErrorString(e));
+  return FDNN_OK;
+}
+
+int fdnn_debug_production_acc_out(fdnn_model *m, const float *x, int n, int stride, const int8_t *masks, int32_t *acc, float *probs) {
+  if (!m || !x || !acc || n <= 0 || stride <= 0) return fail(FDNN_E_ARG, "bad argument");
+  DeviceGuard g(m->device);
+  const BlobHeader &h = m->hm.hdr;
+  const size_t O = size_t(h.out_dim), N = size_t(n), NP = size_t((n + stride - 1) / stride);
+  fdnn_ctx *c = nullptr;
+  int rc = make_ctx(m, n, &c);
+  if (rc) return rc;
+  Taps t{};  // only the probe: hidden layers and output layer run their production instances
+  t.probe_stride = stride;
+  hipStream_t s = c->stream;
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&t.acc_probe), sizeof(int32_t) * NP * O);
+  if (e == hipSuccess) e = hipMemsetAsync(t.acc_probe, 0xff, sizeof(int32_t) * NP * O, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x, sizeof(float) * N * h.in_dim, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && masks) e = hipMemcpyAsync(c->d_mask, masks, N * O, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    rc = run_hidden(c, c->d_x, s, nullptr);
+    if (!rc) rc = run_output(c, 0, n, masks ? c->d_mask : nullptr, c->d_out, s, &t);
+  }
+  if (e == hipSuccess && !rc) e = hipMemcpyAsync(acc, t.acc_probe, sizeof(int32_t) * NP * O, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && !rc && probs) e = hipMemcpyAsync(probs, c->d_out, sizeof(float) * N * O, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(t.acc_probe);
+  fdnn_ctx_free(c);
+  if (rc) return rc;
+  if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("acc probe: ") + hipGetErrorString(e));
   return FDNN_OK;
 }
 

@@ -322,6 +322,9 @@ __global__ __launch_bounds__(kSmThreads, 2) void qgemm_small_kernel(QGemmParams 
       } else {
         // z = sum/coef + bias (masked-out nodes keep z = 0, dnn.cc:366-369), e = exp(z) (dnn.cc:536-540): the
         // operations of the large-batch kernel's dense instance, one for one
+        if (p.acc_probe != nullptr && ff < p.n && ff % p.probe_stride == 0)  // parity tests only (see QGemmParams)
+          for (int i = 0; i < 4; ++i)
+            if (nb + i < p.rows) p.acc_probe[static_cast<size_t>(ff / p.probe_stride) * p.rows + nb + i] = sv[i];
         uint32_t mbits = 0x01010101u;
         if (MASKED && p.mask != nullptr && ff < p.n) {
           mbits = 0;

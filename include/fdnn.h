@@ -231,9 +231,16 @@ FDNN_API int fdnn_model_import_blob(const void *d_src, size_t bytes, int device,
 FDNN_API int fdnn_debug_forward_taps(fdnn_model *m, const float *x, int n, const int8_t *masks, float *l0_lin,
                                      uint8_t *u8_acts, int32_t *acc_hid, int32_t *acc_out, float *logits, float *probs);
 
+/* The int32 accumulators of the output layer as the PRODUCTION kernel instances hold them (no tap kernels anywhere on
+ * the path: the dense / masked instance a plain call of the same size launches), for every stride-th frame:
+ * acc [ceil(n/stride)][O].  probs (may be NULL) receives the call's ordinary result [n][O].  Parity tests only. */
+FDNN_API int fdnn_debug_production_acc_out(fdnn_model *m, const float *x, int n, int stride, const int8_t *masks, int32_t *acc,
+                                           float *probs);
+
 /* Which kernel computes the canonical fp32 input layer (tests / measurements only; results are
  * bit-identical): 0 = by batch size (default), 1 = always the chain-pass kernel (128 x 128
- * tiles over chain-major images), 2 = always the 64 x 64-tile kernel. */
+ * tiles over chain-major images), 2 = always the 64 x 64-tile kernel, 3 = the screened matrix-pipe path wherever it is
+ * available (batches of 2048 frames and more, no taps). */
 FDNN_API int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind);
 
 /* Layer 0 alone through the PRODUCTION kernels (no taps): u8_out [n][hidden_dim].  Large batches take the

@@ -114,6 +114,29 @@ def test_mid_lazy_golden(mid_model_path, x16):
     dnn.delete()
 
 
+@pytest.mark.parametrize("frames", [8, 16, 32])
+def test_decoder_sized_lazy_blocks_on_the_full_net(net_model_path, frames):
+    """The batched alternative to the per-frame calculateLazy (one JNI round trip and ~35 us per frame through the host
+    API, README.md:45): a decoder hands over a block of 8..32 frames with their masks (FuncTest.generateMasks: 40 %
+    active, 3 % churn per frame).  Full 8000-output net, small-batch kernels, against the oracle's
+    LazyOutputActivations (dnn.cc:355-392) -- and bit for bit against the per-frame entry point."""
+    n = frames
+    x = F.synth_features(n, 432, seed=123 + frames)
+    masks = F.generate_masks(n, 8000, 0.40, 0.03, seed=17)
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    ctx = dnn.getNewLazyContext(n)
+    ctx.calculateUntilOutput(x)
+    block = ctx.calculateForOutputNodesBatch(masks)
+    rows = np.stack([ctx.calculateForOutputNodes(masks[i]) for i in range(n)])
+    ctx.delete()
+    dnn.delete()
+    want = Oracle(net_model_path).lazy(x, masks)
+    assert np.abs(block - want).max() <= TIGHT
+    assert np.array_equal(block, rows)
+    off = block[0][masks[0] == 0]
+    assert off.min() > 0 and np.all(off == off[0])  # masked-out nodes: exp(0) / total each
+
+
 def test_full_net_hashes(net_model_path):
     g = golden("net_full.npz")
     dnn = api.QuantizedDnn.loadFromFile(net_model_path)
@@ -338,6 +361,41 @@ def test_cli_matches_oracle(tmp_path, mid_model_path, x16):
     txt = np.loadtxt(out_txt, dtype=np.float32)
     assert txt.shape == (100, 1000) and np.abs(txt - want).max() <= 1e-5  # 6 significant digits
     assert subprocess.run([cli, mid_model_path], capture_output=True).returncode != 0
+    # ... and against the reference's own CLI (oracle/_ref/fast-dnn, compiled from the reference's sources where they
+    # were available: it travels with the repo as a binary): same console lines, same output file layout, same numbers
+    ref_cli = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle", "_ref", "fast-dnn")
+    if os.path.exists(ref_cli):
+        ref_bin, ref_txt = str(tmp_path / "r.bin"), str(tmp_path / "r.txt")
+        rr = subprocess.run([ref_cli, mid_model_path, inp, ref_bin, "BIN"], capture_output=True, text=True, check=True)
+        subprocess.run([ref_cli, mid_model_path, inp, ref_txt, "TXT"], check=True, capture_output=True)
+        keep = lambda text: [ln for ln in text.splitlines() if ln.startswith(("Network", "Input   "))]
+        assert keep(r.stdout) == keep(rr.stdout), (r.stdout, rr.stdout)
+        ref = F.read_output_matrix(ref_bin)
+        assert ref.shape == got.shape and np.abs(got - ref).max() <= TIGHT
+        with open(out_bin, "rb") as fa, open(ref_bin, "rb") as fb:
+            assert fa.read(8) == fb.read(8)  # host-endian u32 frame / dimension header (float_dnn.cc:140-150)
+        ref_t = np.loadtxt(ref_txt, dtype=np.float32)
+        assert ref_t.shape == txt.shape and np.abs(txt - ref_t).max() <= 1e-5
+
+
+def test_config1_16khz_frames_tiled_to_1000_on_the_full_net(net_model_path, x16):
+    """BASELINE configs[1], literally: the shipped data/16khz.bin frames (100 valid rows; golden x16) tiled x10 to a
+    1000-frame batch, full soft-max, on the full 432 -> 7x2048 -> 8000 net, against the oracle:
+    last hidden layer bit for bit, probabilities within 2e-6; and every repetition of a frame gets the same bits."""
+    x = np.tile(x16, (10, 1))
+    assert x.shape == (1000, 432)
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    got = dnn.calculate(x)
+    ctx = dnn.getNewLazyContext(1000)
+    ctx.calculateUntilOutput(x)
+    hid = ctx.hiddenActivations()
+    ctx.delete()
+    dnn.delete()
+    want, wt = Oracle(net_model_path).calculate(x16, taps=True)   # the 100 distinct frames
+    assert np.array_equal(hid[:100], wt["u8_acts"][-1])
+    assert np.abs(got[:100] - want).max() <= TIGHT
+    for r in range(1, 10):
+        assert np.array_equal(got[100 * r:100 * r + 100], got[:100]) and np.array_equal(hid[100 * r:100 * r + 100], hid[:100])
 
 
 def test_quantization_error_against_the_float_net(mid_model_path, x16):

@@ -257,3 +257,44 @@ def test_screened_layer0_is_bit_exact(net_model_path, tmp_models, seed, scale):
     chain, rec2 = dnn.layer0(x)
     assert rec2 == 0 and np.array_equal(chain, got)
     dnn.delete()
+
+
+def test_screened_layer0_with_a_wide_input_is_bit_exact(tmp_models):
+    """The screened path's error bound carries a term that grows with the square of the input width
+    ((D^2/2 + 2D) u^2 S: the unfused chain's own partial sums against the sampled fused ones), which at the
+    432-wide benchmark input hides inside the bound's slack and at 2048 does not.  A 2048-wide input layer,
+    2304 frames (screened path: large batch, no taps), every activation byte against the oracle."""
+    p = os.path.join(tmp_models, "wide_in.bin")
+    F.write_model_bin(p, F.synth_net([2048, 256, 256, 256, 64], seed=21, w0_std=0.01))
+    n = 2304
+    x = F.synth_features(n, 2048, seed=9, pad_from=None)
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    dnn.setInputLayerKernel(3)  # on a layer this narrow the cost model would pick the chain kernel
+    got, recomputed = dnn.layer0(x)
+    assert 0 < recomputed < 0.5 * n * 256, recomputed
+    orc = Oracle(p)
+    for lo in range(0, n, 768):
+        _, t = orc.calculate(x[lo:lo + 768], taps=True)
+        bad = np.argwhere(got[lo:lo + 768] != t["u8_acts"][0])
+        assert bad.size == 0, (lo, bad[:5].tolist())
+    dnn.delete()
+
+
+@pytest.mark.parametrize("n,stride", [(10000, 41), (100, 7)])
+def test_production_output_instance_accumulators_are_bit_exact(net_model_path, n, stride):
+    """The int32 accumulators of the output layer, 8000 nodes wide, out of the PRODUCTION kernel instances (the
+    branch-free dense instance of the 10 000-frame batch; the small-batch kernel at 100 frames) -- not the tap kernels,
+    which are different instances: every stride-th frame's 8000 sums against the oracle's quantizedNodeSum values
+    (dnn.cc:323-349, pair saturation included), bit for bit.  A wrong low bit of one accumulator would hide inside
+    the 2e-6 the soft-max comparison allows."""
+    x = F.synth_features(n, 432, seed=77)
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    acc, probs = dnn.productionOutputAcc(x, stride, probs=True)
+    plain = dnn.calculate(x)
+    dnn.delete()
+    assert np.array_equal(probs, plain)           # the probe does not change what the call returns
+    idx = np.arange(0, n, stride)
+    assert acc.shape == (len(idx), 8000)
+    want, wt = Oracle(net_model_path).calculate(x[idx], taps=True)
+    assert np.array_equal(acc, wt["acc_out"]), np.argwhere(acc != wt["acc_out"])[:5].tolist()
+    assert np.abs(probs[idx] - want).max() <= 2e-6

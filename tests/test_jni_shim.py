@@ -33,6 +33,10 @@ def test_java_facade_sequence(tiny_model_path):
     assert dnn.calculate([])[0:0].shape[0] == 0
     with pytest.raises(ValueError):
         dnn.calculate(np.zeros((2, 429), np.float32))
+    # a result that cannot be a Java float[] (jsize is 32 bits: 2^31 - 1 elements) is refused before anything is touched
+    with pytest.raises(JavaException) as e:
+        dnn._call("calculate", dnn.handle, jvm.new_object(np.zeros(432, np.float32)), 21_474_837, 432, 10)  # x 100 outputs > 2^31 - 1
+    assert e.value.cls == "java/lang/IllegalArgumentException" and "Java float[]" in str(e.value)
     # lazy protocol, FuncTest.java:104-112
     masks = F.generate_masks(100, 100, 0.4, 0.03, seed=5)
     ctx = dnn.getNewLazyContext(100)
