@@ -86,6 +86,7 @@ SIGNATURES = {
     "fdnn_group_size": (C.c_int, [C.c_void_p]),
     "fdnn_group_model": (C.c_void_p, [C.c_void_p, C.c_int]),
     "fdnn_group_weight_transport": (C.c_char_p, [C.c_void_p]),
+    "fdnn_group_worker_cpus": (C.c_char_p, [C.c_void_p, C.c_int]),
     "fdnn_group_calculate": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, C.c_int, _c_f32p]),
     "fdnn_group_shard": (None, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "fdnn_group_attach": (C.c_int, [C.c_void_p]),
@@ -263,6 +264,10 @@ class DeviceGroup:
 
     def weightTransport(self) -> str:
         return lib().fdnn_group_weight_transport(self.handle).decode()
+
+    def workerCpus(self, index: int) -> str:
+        """CPU list replica `index`'s persistent host thread pinned itself to ("" before the first large call)."""
+        return lib().fdnn_group_worker_cpus(self.handle, int(index)).decode()
 
     def calculate(self, input, batchSize: int = 10) -> np.ndarray:
         x = np.asarray(input, dtype=np.float32)

@@ -12,16 +12,30 @@
 //               dlopen'ed, not linked: a process that also holds PyTorch must not see two RCCLs)
 //               -- and each peer adopts it (fdnn_model_import_blob), so all replicas hold
 //               bit-identical weights.
-//   calculate:  contiguous frame shards (sizes differ by at most one frame, the same rule as
-//               dist.frame_shards), one host thread per device, each shard through the ordinary
-//               single-device path into its slice of the caller's output.  No collective, no
-//               device-to-device traffic in steady state: frames are independent.
+//   calculate:  a LARGE call is cut into contiguous frame shards (sizes differ by at most one frame, the same rule
+//               as dist.frame_shards), one shard per device, each through the ordinary single-device path into its
+//               slice of the caller's output, on that device's own persistent host thread (pinned to the CPUs of
+//               the device's NUMA node, so that its staging copies stay local).  A SMALL call -- the JNI serving
+//               shape: 100-frame utterances from many Java threads -- stays whole and goes to ONE replica, chosen
+//               round robin, on the caller's own thread: eight devices then serve eight callers at a time instead
+//               of every call paying eight thread hand-offs, eight H2D copies and 72 launches for 12 frames each.
+//               No collective, no device-to-device traffic in steady state: frames are independent.
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
 
+#include <pthread.h>
+#include <sched.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -31,10 +45,25 @@
 using fdnn::DeviceGuard;
 using fdnn::fail;
 
+// One persistent host thread per replica: runs the shards of large calls on its device.
+struct GroupWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> jobs;
+  bool stop = false;
+  std::string cpus;  // the CPU list it pinned itself to ("" = not pinned)
+};
+
 struct fdnn_group {
   std::vector<fdnn_model *> models;  // models[0] = leader (quantized the weights)
   std::vector<int> devices;
   std::string bcast;                 // how the weights travelled: "peer-copy" | "rccl" | "none"
+  std::vector<GroupWorker *> workers;  // started on the first large call
+  std::mutex workers_mu;
+  std::atomic<unsigned> next_replica{0};  // round robin of the small calls
+  int split_min = 4096;              // calls of fewer frames stay on one device (FDNN_GROUP_SPLIT_MIN)
+  int shard_min = 1024;              // a shard is at least this many frames (fewer devices take part otherwise)
 };
 
 namespace {
@@ -108,6 +137,94 @@ bool rccl_broadcast(const std::vector<int> &devs, const std::vector<void *> &buf
   return ok;
 }
 
+
+// "0-15,128-143" -> the calling thread's affinity mask; false when nothing usable was parsed
+bool pin_to_cpulist(const std::string &list) {
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int found = 0;
+  for (const char *q = list.c_str(); *q;) {
+    char *end = nullptr;
+    const long a = std::strtol(q, &end, 10);
+    if (end == q) break;
+    long b = a;
+    q = end;
+    if (*q == '-') {
+      b = std::strtol(q + 1, &end, 10);
+      q = end;
+    }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) {
+      CPU_SET(static_cast<int>(c), &set);
+      ++found;
+    }
+    if (*q == ',') ++q;
+  }
+  return found > 0 && pthread_setaffinity_np(pthread_self(), sizeof(set), &set) == 0;
+}
+
+// CPUs local to the device's PCIe root (its NUMA node): /sys/bus/pci/devices/<bus id>/local_cpulist
+std::string device_local_cpus(int device) {
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) return "";
+  for (char *c = bus; *c; ++c)
+    if (*c >= 'A' && *c <= 'Z') *c = static_cast<char>(*c - 'A' + 'a');
+  const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+  std::string out;
+  if (FILE *f = std::fopen(path.c_str(), "r")) {
+    char buf[512];
+    if (std::fgets(buf, sizeof(buf), f)) out = buf;
+    std::fclose(f);
+  }
+  while (!out.empty() && (out.back() == '\n' || out.back() == ' ')) out.pop_back();
+  return out;
+}
+
+void worker_loop(GroupWorker *w, int device) {
+  static const bool no_pin = std::getenv("FDNN_GROUP_NO_PIN") != nullptr;
+  if (!no_pin) {
+    const std::string cpus = device_local_cpus(device);
+    if (!cpus.empty() && pin_to_cpulist(cpus)) {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->cpus = cpus;
+    }
+  }
+  for (;;) {
+    std::function<void()> job;
+    {
+      std::unique_lock<std::mutex> lk(w->mu);
+      w->cv.wait(lk, [&] { return w->stop || !w->jobs.empty(); });
+      if (w->jobs.empty()) return;  // stop, and nothing left to run
+      job = std::move(w->jobs.front());
+      w->jobs.pop_front();
+    }
+    job();
+  }
+}
+
+void start_workers(fdnn_group *g) {
+  std::lock_guard<std::mutex> lk(g->workers_mu);
+  if (!g->workers.empty()) return;
+  for (size_t r = 0; r < g->models.size(); ++r) {
+    GroupWorker *w = new GroupWorker();
+    w->th = std::thread(worker_loop, w, g->devices[r]);
+    g->workers.push_back(w);
+  }
+}
+
+void stop_workers(fdnn_group *g) {
+  std::lock_guard<std::mutex> lk(g->workers_mu);
+  for (GroupWorker *w : g->workers) {
+    {
+      std::lock_guard<std::mutex> l2(w->mu);
+      w->stop = true;
+    }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+    delete w;
+  }
+  g->workers.clear();
+}
+
 }  // namespace
 
 namespace fdnn {
@@ -131,6 +248,8 @@ int fdnn_group_load(const char *path, float cutoff, const int *devices, int n_de
   if (n_devices < 1 || n_devices > 64) return fail(FDNN_E_ARG, "a group holds 1..64 devices");
   fdnn_group *g = new fdnn_group();
   g->devices.assign(devices, devices + n_devices);
+  if (const char *e = std::getenv("FDNN_GROUP_SPLIT_MIN")) g->split_min = std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("FDNN_GROUP_SHARD_MIN")) g->shard_min = std::max(1, std::atoi(e));
   fdnn_model *leader = nullptr;
   int rc = fdnn_model_load_on(path, cutoff, devices[0], &leader);
   if (rc) {
@@ -178,6 +297,12 @@ int fdnn_group_load(const char *path, float cutoff, const int *devices, int n_de
     fdnn_model *peer = nullptr;
     rc = fdnn_model_import_blob(bufs[size_t(i)], bytes, devices[i], &peer);
     if (!rc) g->models.push_back(peer);
+    // FDNN_BATCHER on every replica or on none: the leader got its batcher in fdnn_model_load_on
+    if (!rc && leader->batcher) {
+      int mf = 0, depth = 2, linger = 0;
+      const char *env = std::getenv("FDNN_BATCHER");
+      if (env && std::sscanf(env, "%d:%d:%d", &mf, &depth, &linger) >= 1 && mf > 0) rc = fdnn_model_enable_batcher(peer, mf, depth, linger);
+    }
   }
   for (int i = 1; i < n_devices; ++i)
     if (bufs[size_t(i)]) {
@@ -194,6 +319,7 @@ int fdnn_group_load(const char *path, float cutoff, const int *devices, int n_de
 
 void fdnn_group_free(fdnn_group *g) {
   if (!g) return;
+  stop_workers(g);
   for (fdnn_model *m : g->models) {
     if (m->group == g) m->group = nullptr;
     fdnn_model_free(m);
@@ -219,24 +345,62 @@ int fdnn_group_calculate(fdnn_group *g, const float *x, int n, int dim, int batc
   if (dim != D)
     return fail(FDNN_E_ARG, "input vector size " + std::to_string(dim) + " must be equal with network input size " + std::to_string(D));
   const int world = int(g->models.size());
-  std::vector<int> rcs(size_t(world), FDNN_OK);
-  std::vector<std::string> msgs(static_cast<size_t>(world));
-  auto shard = [&](int r) {
-    int a, b;
-    fdnn::frame_shard(n, world, r, &a, &b);
-    if (b == a) return;
-    fdnn_model *m = g->models[size_t(r)];
+  // small call: whole, on one replica (round robin), on the caller's thread
+  if (world == 1 || n < g->split_min) {
+    const unsigned r = world == 1 ? 0u : g->next_replica.fetch_add(1, std::memory_order_relaxed) % unsigned(world);
+    fdnn_model *m = g->models[r];
     m->l0_fma = leader->l0_fma;  // one numeric flavour per group
-    rcs[size_t(r)] = fdnn::calculate_on_one_device(m, x + size_t(a) * D, b - a, dim, batch_hint, out + size_t(a) * O);
-    if (rcs[size_t(r)]) msgs[size_t(r)] = fdnn_last_error();  // thread-local: carry it to the caller
-  };
-  std::vector<std::thread> th;
-  for (int r = 1; r < world; ++r) th.emplace_back(shard, r);
-  shard(0);
-  for (auto &t : th) t.join();
-  for (int r = 0; r < world; ++r)
-    if (rcs[size_t(r)]) return fail(rcs[size_t(r)], "device " + std::to_string(g->devices[size_t(r)]) + ": " + msgs[size_t(r)]);
+    return fdnn::calculate_on_one_device(m, x, n, dim, batch_hint, out);
+  }
+  // large call: contiguous shards over as many replicas as keep a shard at shard_min frames or more, each on its
+  // device's persistent worker; the caller waits
+  const int use = std::max(1, std::min(world, n / std::max(1, g->shard_min)));
+  start_workers(g);
+  const unsigned first = g->next_replica.fetch_add(unsigned(use), std::memory_order_relaxed);
+  std::vector<int> rcs(size_t(use), FDNN_OK);
+  std::vector<std::string> msgs(static_cast<size_t>(use));
+  std::mutex done_mu;
+  std::condition_variable done_cv;
+  int left = use;
+  for (int k = 0; k < use; ++k) {
+    const int r = int((first + unsigned(k)) % unsigned(world));
+    int a, b;
+    fdnn::frame_shard(n, use, k, &a, &b);
+    GroupWorker *w = g->workers[size_t(r)];
+    auto job = [&, k, r, a, b] {
+      if (b > a) {
+        fdnn_model *m = g->models[size_t(r)];
+        m->l0_fma = leader->l0_fma;
+        rcs[size_t(k)] = fdnn::calculate_on_one_device(m, x + size_t(a) * D, b - a, dim, batch_hint, out + size_t(a) * O);
+        if (rcs[size_t(k)]) msgs[size_t(k)] = fdnn_last_error();  // thread-local: carry it to the caller
+      }
+      std::lock_guard<std::mutex> lk(done_mu);
+      if (--left == 0) done_cv.notify_all();
+    };
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->jobs.emplace_back(job);
+    }
+    w->cv.notify_one();
+  }
+  {
+    std::unique_lock<std::mutex> lk(done_mu);
+    done_cv.wait(lk, [&] { return left == 0; });
+  }
+  for (int k = 0; k < use; ++k)
+    if (rcs[size_t(k)])
+      return fail(rcs[size_t(k)], "device " + std::to_string(g->devices[size_t((first + unsigned(k)) % unsigned(world))]) + ": " + msgs[size_t(k)]);
   return FDNN_OK;
+}
+
+// Where the worker thread of replica `index` pinned itself ("" = no worker yet / not pinned).  Diagnostics.
+const char *fdnn_group_worker_cpus(fdnn_group *g, int index) {
+  if (!g || index < 0) return "";
+  std::lock_guard<std::mutex> lk(g->workers_mu);
+  if (size_t(index) >= g->workers.size()) return "";
+  GroupWorker *w = g->workers[size_t(index)];
+  std::lock_guard<std::mutex> l2(w->mu);
+  return w->cpus.c_str();
 }
 
 void fdnn_group_shard(int n, int world, int rank, int *start, int *stop) {

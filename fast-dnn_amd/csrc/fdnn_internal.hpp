@@ -108,7 +108,9 @@ struct Taps {
   int probe_stride = 1;
 };
 
-int make_ctx(fdnn_model *m, int n, fdnn_ctx **out);
+// lean: a scoring-loop slot -- no frame / result / mask buffers and no per-frame pinned staging of its own (device
+// submissions bring their buffers; the host path allocates what it needs in alloc_host_side)
+int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean = false);
 void destroy_ctx(fdnn_ctx *c);
 // CalculateUntilLastHiddenLayer (dnn.cc:402-424) enqueued on s.
 int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps);

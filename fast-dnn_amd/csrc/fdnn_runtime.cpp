@@ -147,7 +147,7 @@ void destroy_ctx(fdnn_ctx *c) {
   delete c;
 }
 
-int make_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
+int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
   DeviceGuard g(m->device);
   if (!g.ok) return fail(FDNN_E_DEVICE, "hipSetDevice failed");
   const BlobHeader &h = m->hm.hdr;
@@ -168,7 +168,7 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
   auto alloc = [&](void **p, size_t bytes) {
     if (e == hipSuccess) e = hipMalloc(p, bytes ? bytes : 16);
   };
-  alloc(reinterpret_cast<void **>(&c->d_x), sizeof(float) * np * h.in_dim);
+  if (!lean) alloc(reinterpret_cast<void **>(&c->d_x), sizeof(float) * np * h.in_dim);
   c->xt_ld = round_up(c->cap, 128);
   alloc(reinterpret_cast<void **>(&c->d_xt), sizeof(float) * 4 * size_t(m->l0_j_pad) * c->xt_ld);
   {  // screened layer-0 path: the per-tile lists of outputs to recompute exactly
@@ -181,16 +181,16 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
     alloc(reinterpret_cast<void **>(&c->d_l0park), sizeof(float) * size_t(c->xt_ld) * m->l0_h_ld);
   alloc(reinterpret_cast<void **>(&c->d_act[0]), npt * c->act_ld);
   alloc(reinterpret_cast<void **>(&c->d_act[1]), npt * c->act_ld);
-  alloc(reinterpret_cast<void **>(&c->d_out), sizeof(float) * np * h.out_dim);
+  if (!lean) alloc(reinterpret_cast<void **>(&c->d_out), sizeof(float) * np * h.out_dim);
   alloc(reinterpret_cast<void **>(&c->d_partial), sizeof(float) * npt * (max_rows_pad / fdnn::kPartialNodes));
-  alloc(reinterpret_cast<void **>(&c->d_mask), np * h.out_dim);
+  if (!lean) alloc(reinterpret_cast<void **>(&c->d_mask), np * h.out_dim);
   alloc(reinterpret_cast<void **>(&c->d_mask_bits), sizeof(uint64_t) * np * size_t((h.out_dim + 63) / 64));
-  if (e == hipSuccess)  // at least one padded row: the one-frame kernel reads the mask in 16-byte pieces up to rows_pad
+  if (e == hipSuccess && !lean)  // at least one padded row: the one-frame kernel reads the mask in 16-byte pieces up to rows_pad
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mask_pin), std::max(size_t(kPinFrames) * h.out_dim, size_t(max_rows_pad)), hipHostMallocMapped);
-  if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_mask_pin), c->h_mask_pin, 0);
-  if (e == hipSuccess)
+  if (e == hipSuccess && !lean) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_mask_pin), c->h_mask_pin, 0);
+  if (e == hipSuccess && !lean)
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_out_pin), sizeof(float) * kPinFrames * h.out_dim, hipHostMallocMapped);
-  if (e == hipSuccess) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_out_pin), c->h_out_pin, 0);
+  if (e == hipSuccess && !lean) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_out_pin), c->h_out_pin, 0);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
   if (e != hipSuccess) {

@@ -57,7 +57,10 @@ struct TicketState {
   int status = 0;      // 0 running, != 0 failed with that fdnn_status
   int created = 0;     // pieces packed so far
   int done = 0;        // pieces copied out
-  bool closed = false; // the final piece has been packed
+  int failed = 0;      // pieces lost with their batch (never copied)
+  bool closed = false; // the final piece has been packed, or the rest of the request was dropped after a failure
+  // a piece is in flight while created > done + failed: wait() does not hand a failed ticket back to its caller before
+  // that is over -- the packer still reads the caller's frames and the copy threads still write the caller's rows
 };
 
 struct Request {
@@ -98,6 +101,7 @@ struct fdnn_server {
   // host path
   std::mutex qmu;
   std::condition_variable qcv, done_cv, slot_cv;
+  bool packer_done = false;       // set by fdnn_server_free once the packer thread has been joined (under qmu)
   std::deque<Request> queue;
   std::deque<int> flying;         // slots with a host batch enqueued, in launch order
   std::unordered_map<uint64_t, TicketState> pending;  // host tickets not yet complete (a failed one stays until waited for)
@@ -118,6 +122,9 @@ int alloc_host_side(fdnn_server *s) {
     hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_x), sizeof(float) * n * h.in_dim, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_mask), n * h.out_dim, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&sl.d_out), sizeof(float) * n * h.out_dim);
+    // the slot's context was made lean: the device-side landing buffers of host batches live here
+    if (e == hipSuccess && !sl.ctx->d_x) e = hipMalloc(reinterpret_cast<void **>(&sl.ctx->d_x), sizeof(float) * n * h.in_dim);
+    if (e == hipSuccess && !sl.ctx->d_mask) e = hipMalloc(reinterpret_cast<void **>(&sl.ctx->d_mask), n * h.out_dim);
     if (e != hipSuccess)
       return fail(e == hipErrorOutOfMemory ? FDNN_E_NOMEM : FDNN_E_DEVICE, std::string("server staging: ") + hipGetErrorString(e));
   }
@@ -177,6 +184,19 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
   return FDNN_OK;
 }
 
+// A batch carrying `ticket` failed: whatever of that request is still queued will never be packed (the packer would read
+// caller memory that the caller, told of the failure, is free to release).  Call with qmu held.
+void drop_queued_rest(fdnn_server *s, uint64_t ticket) {
+  for (auto it = s->queue.begin(); it != s->queue.end();) {
+    if (it->ticket == ticket)
+      it = s->queue.erase(it);
+    else
+      ++it;
+  }
+  auto t = s->pending.find(ticket);
+  if (t != s->pending.end()) t->second.closed = true;
+}
+
 // Hands rows back to their callers.  The rows of a finished batch sit in the slot's device buffer; whoever gets
 // there first copies a piece out -- the caller blocked in fdnn_server_wait (so that many callers copy in
 // parallel: 3.2 MB per 100-frame utterance, one thread's copies would be the slowest stage of the loop) or the
@@ -205,7 +225,10 @@ void copy_ready_pieces(fdnn_server *s, std::unique_lock<std::mutex> &lk, Slot &s
     bool finished = false;
     if (it != s->pending.end()) {
       it->second.done++;
-      if (ce != hipSuccess) it->second.status = FDNN_E_DEVICE;
+      if (ce != hipSuccess) {
+        it->second.status = FDNN_E_DEVICE;
+        drop_queued_rest(s, job.ticket);
+      }
       if (it->second.closed && it->second.done == it->second.created && it->second.status == 0) {
         s->pending.erase(it);
         finished = true;
@@ -327,7 +350,11 @@ void packer_loop(fdnn_server *s) {
         sl.pieces_left = 0;
         for (const Piece &p : sl.pieces) {
           auto it = s->pending.find(p.ticket);
-          if (it != s->pending.end()) it->second.status = rc;
+          if (it != s->pending.end()) {
+            it->second.status = rc;
+            it->second.failed++;
+            drop_queued_rest(s, p.ticket);
+          }
         }
       } else {
         s->flying.push_back(si);
@@ -349,9 +376,11 @@ void finisher_loop(fdnn_server *s) {
     int si;
     {
       std::unique_lock<std::mutex> lk(s->qmu);
-      s->qcv.wait(lk, [&] { return s->stop || !s->flying.empty(); });
+      // (the finisher outlives the packer: at shutdown the packer still drains the queue, and a batch it enqueues after the
+      // finisher had gone would never be marked ready or scattered)
+      s->qcv.wait(lk, [&] { return (s->stop && s->packer_done) || !s->flying.empty(); });
       if (s->flying.empty()) {
-        if (s->stop) return;
+        if (s->stop && s->packer_done) return;
         continue;
       }
       si = s->flying.front();
@@ -364,7 +393,11 @@ void finisher_loop(fdnn_server *s) {
       for (Piece &p : sl.pieces) {
         p.state = 3;
         auto it = s->pending.find(p.ticket);
-        if (it != s->pending.end()) it->second.status = FDNN_E_DEVICE;
+        if (it != s->pending.end()) {
+          it->second.status = FDNN_E_DEVICE;
+          it->second.failed++;
+          drop_queued_rest(s, p.ticket);
+        }
       }
       sl.pieces_left = 0;
       sl.in_flight = false;
@@ -413,7 +446,7 @@ int fdnn_server_create(fdnn_model *m, int max_frames, int depth, fdnn_server **o
   int rc = FDNN_OK;
   for (Slot &sl : s->slots) {
     if (e != hipSuccess || rc) break;
-    rc = fdnn::make_ctx(m, max_frames, &sl.ctx);
+    rc = fdnn::make_ctx(m, max_frames, &sl.ctx, /*lean=*/true);
     if (rc) break;
     e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.gemm_done, hipEventDisableTiming);
@@ -440,6 +473,11 @@ void fdnn_server_free(fdnn_server *s) {
   s->qcv.notify_all();
   s->slot_cv.notify_all();
   if (s->packer.joinable()) s->packer.join();
+  {
+    std::lock_guard<std::mutex> lk(s->qmu);
+    s->packer_done = true;
+  }
+  s->qcv.notify_all();
   if (s->finisher.joinable()) s->finisher.join();
   for (Slot &sl : s->slots) {
     if (sl.used && sl.done) hipEventSynchronize(sl.done);
@@ -543,8 +581,8 @@ int fdnn_server_wait(fdnn_server *s, uint64_t ticket) {
       for (;;) {
         auto it = s->pending.find(ticket);
         if (it == s->pending.end()) return FDNN_OK;  // complete (the last piece was copied, here or by the finisher)
-        if (it->second.status != 0) {
-          const int status = it->second.status;
+        if (it->second.status != 0 && it->second.closed && it->second.created == it->second.done + it->second.failed) {
+          const int status = it->second.status;  // no piece of it is queued or in flight any more
           s->pending.erase(it);
           return fail(status, "a batch carrying this ticket failed on the device");
         }
@@ -580,8 +618,11 @@ int fdnn_server_drain(fdnn_server *s) {
   {
     std::unique_lock<std::mutex> lk(s->qmu);
     s->done_cv.wait(lk, [&] {
-      for (const auto &kv : s->pending)
-        if (kv.second.status == 0) return false;
+      for (auto it = s->pending.begin(); it != s->pending.end();) {
+        const TicketState &t = it->second;
+        if (t.status == 0 || !t.closed || t.created != t.done + t.failed) return false;  // running, or pieces still in flight
+        it = s->pending.erase(it);  // failed and quiescent, nobody waited for it: forget it
+      }
       return true;
     });
   }

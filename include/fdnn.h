@@ -204,6 +204,9 @@ FDNN_API void fdnn_group_free(fdnn_group *g);
 FDNN_API int fdnn_group_size(const fdnn_group *g);
 FDNN_API fdnn_model *fdnn_group_model(const fdnn_group *g, int index);
 FDNN_API const char *fdnn_group_weight_transport(const fdnn_group *g); /* "none" | "peer-copy" | "rccl" */
+/* CPU list the persistent host thread of replica `index` pinned itself to (its device's NUMA-local CPUs), "" before the
+ * first large call or when the list could not be read.  Diagnostics. */
+FDNN_API const char *fdnn_group_worker_cpus(fdnn_group *g, int index);
 FDNN_API int fdnn_group_calculate(fdnn_group *g, const float *x, int n, int dim, int batch_hint, float *out);
 FDNN_API void fdnn_group_shard(int n, int world, int rank, int *start, int *stop);
 FDNN_API int fdnn_group_attach(fdnn_group *g);

@@ -17,7 +17,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
-def test_group_equals_single_device(mid_model_path, devices):
+def test_group_equals_single_device(mid_model_path, devices, monkeypatch):
+    # (thresholds are read when the group is created: make a 1001-frame call a "large" one, so that it is sharded)
+    monkeypatch.setenv("FDNN_GROUP_SPLIT_MIN", "64")
+    monkeypatch.setenv("FDNN_GROUP_SHARD_MIN", "16")
     x = F.synth_features(1001, 432, seed=88)   # ragged shards
     one = api.QuantizedDnn.loadFromFile(mid_model_path, device=0)
     want = one.calculate(x)
@@ -39,6 +42,39 @@ def test_group_equals_single_device(mid_model_path, devices):
     grp.model(0).setInputLayerFma(True)
     one.setInputLayerFma(True)
     assert np.array_equal(grp.calculate(x), one.calculate(x))
+    grp.delete()
+    one.delete()
+
+
+def test_group_routes_small_calls_whole_and_large_calls_over_persistent_workers(mid_model_path):
+    """Default thresholds: a call of fewer than 4096 frames stays whole on ONE replica (round robin; the JNI serving
+    shape: many Java threads with 100-frame utterances), a larger one is cut into shards of at least 1024 frames that
+    run on the devices' persistent, NUMA-pinned host threads.  Results are the single device's bits either way,
+    also from eight concurrent caller threads."""
+    import threading
+
+    one = api.QuantizedDnn.loadFromFile(mid_model_path, device=0)
+    xs = [F.synth_features(100 + 7 * i, 432, seed=200 + i) for i in range(8)]
+    wants = [one.calculate(x) for x in xs]
+    big = F.synth_features(5000, 432, seed=99)
+    want_big = one.calculate(big)
+    grp = api.DeviceGroup(mid_model_path, [0, 0, 0])
+    assert grp.workerCpus(1) == ""              # no worker threads before the first large call
+    got = [None] * 8
+
+    def caller(i):
+        for _ in range(5):
+            got[i] = grp.calculate(xs[i])
+
+    th = [threading.Thread(target=caller, args=(i,)) for i in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(8):
+        assert np.array_equal(got[i], wants[i])
+    assert np.array_equal(grp.calculate(big), want_big)      # 5000 frames: three shards (1667 / 1667 / 1666) on the workers
+    assert np.array_equal(grp.calculate(big[:4500]), want_big[:4500])
+    cpus = [grp.workerCpus(r) for r in range(3)]
+    assert all(isinstance(c, str) for c in cpus)             # "" where /sys has no local_cpulist for the device
     grp.delete()
     one.delete()
 
