@@ -102,8 +102,11 @@ __device__ __forceinline__ v4i read_frag(const char *tile, int row, int chunk) {
 // no taps; the mask only selects z = 0 for inactive nodes (with ANYW for widths % 4 != 0).
 // ANYW (with PLAIN): the dense call for every other output width (pdf counts are arbitrary):
 // per-element range test, 4-byte-aligned dwordx4 stores, scalar stores for a row's last group.
+// FUSED (with OUTPUT, PLAIN, FAST; 8-wave shapes): the soft-max scale inside this kernel -- every workgroup keeps its
+// exp(z) tile in the accumulator registers, the 256-node tiles of a frame tile exchange their row sums through memory,
+// and what leaves is probabilities: no exp(z) round trip through HBM, no normalize pass ("fused soft-max" below).
 template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool TAP, bool FAST, bool PLAIN = false, bool MASKED = false, bool ANYW = false,
-          int WM = 4>
+          int WM = 4, bool FUSED = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (buffer-resource builtins are device-only)
   using Cfg = GemmCfg<NF, WN, BK, STAGES, WM>;
@@ -135,10 +138,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
   // 8000-node output layer read 548 MB per launch with node tiles fastest).
   const int MT = p.rows_pad / G_BM;
   const int NT = p.n_pad / FT;
-  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int per_xcd = (NT + 7) / 8;
-  const int mt = j / per_xcd;
-  const int nt = xcd * per_xcd + j % per_xcd;
+  int mt, nt;
+  if (FUSED) {
+    // fused soft-max: the MT node tiles of a frame tile are CONSECUTIVE workgroups -- dispatched together, resident
+    // together (see the wait below) -- and node tile j of every frame tile lands on XCD j % 8 (for MT % 8 == 0): each
+    // XCD keeps a fixed band of MT / 8 weight tiles in its L2 for the whole launch and streams activation rows.
+    nt = static_cast<int>(blockIdx.x) / MT;
+    mt = static_cast<int>(blockIdx.x) - nt * MT;
+  } else {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int per_xcd = (NT + 7) / 8;
+    mt = j / per_xcd;
+    nt = xcd * per_xcd + j % per_xcd;
+  }
   if (mt >= MT || nt >= NT) return;
   const int m0 = mt * G_BM, f0 = nt * FT;
 
@@ -512,6 +524,153 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
       }
     }
   }
+  if constexpr (FUSED) {
+    static_assert(!FUSED || (OUTPUT && PLAIN && FAST && !MASKED && !ANYW && !TAP && WM == 4), "fused soft-max: the dense production instance only");
+    // ---------------------------------------------------------------- fused soft-max
+    // SoftMax::apply (dnn.cc:534-544) inside the output kernel.  Phase 1: e = exp(z) replaces each accumulator IN
+    // PLACE (160 registers per lane stay live), the 64-node partial sums P are formed exactly as in the unfused
+    // instance.  The workgroup's four P per frame give S = (P0 + P1) + (P2 + P3) -- the first level of the library's
+    // row-total order (normalize_row) -- which it publishes write-through; an arrival counter per frame tile tells when
+    // all MT tiles have; every workgroup then reads the MT vectors of S (40 KB), finishes the tree per frame, and
+    // phase 2 multiplies its e by RN(1 / total) on the way out.  Placement-independent (sc0 sc1 stores and loads on
+    // both sides, one relaxed agent-scope counter); progress: workgroups are dispatched in block order, so the oldest
+    // unfinished frame tile always has all its MT workgroups resident.  Every spin is bounded: a workgroup that gives
+    // up stores exp(z) unscaled and flags its tile for fuse_cleanup_kernel.
+    constexpr int kOS = 64 + 4;
+    float *wtile = reinterpret_cast<float *>(smem + 8192) + wave * (32 * kOS);
+    const int ncol0 = m0 + 64 * wm;
+    constexpr int kFuseOff = 8192 + NW * 32 * kOS * 4;
+    float *Pw = reinterpret_cast<float *>(smem + kFuseOff);  // [4][FT]
+    float *inv_s = Pw + 4 * FT;                               // [FT]
+    int *ok_s = reinterpret_cast<int *>(inv_s + FT);          // [4]
+    float *Sg = inv_s + FT + 4;                               // [L][FT], L = MT rounded up to a power of two
+    int L = 1;
+    while (L < MT) L <<= 1;
+    // (the host launches this instance only when kFuseOff + (5 FT + 4 + L FT) * 4 <= Cfg::FIX_OFF)
+    float ev[2][NF][16];  // exp(z): takes over the accumulators' registers as they die
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = ncol0 + 32 * mi + 8 * g + 4 * half;
+          const v4f_t b4 = *reinterpret_cast<const v4f_t *>(bias_s + (nb - m0));
+          const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
+          const bool in4 = nb < p.rows;
+          typedef float v2f_e __attribute__((ext_vector_type(2)));
+          const v2f_e rcp2 = {p.rcp_coef, p.rcp_coef}, coef2 = {p.coef, p.coef};
+          const v2f_e log2e2 = {1.44269504088896340736f, 1.44269504088896340736f};
+          float e[4];
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {  // the operations of the unfused dense instance, one for one
+            const v2f_e x = {static_cast<float>(acc[mi][ni][g * 4 + 2 * h2]), static_cast<float>(acc[mi][ni][g * 4 + 2 * h2 + 1])};
+            const v2f_e q0 = x * rcp2;
+            const v2f_e r = __builtin_elementwise_fma(-q0, coef2, x);
+            const v2f_e z = __builtin_elementwise_fma(r, rcp2, q0) + v2f_e{bj[2 * h2], bj[2 * h2 + 1]};
+            const v2f_e y = z * log2e2;
+            const v2f_e ev = v2f_e{__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)} * v2f_e{in4 ? 1.0f : 0.0f, in4 ? 1.0f : 0.0f};
+            e[2 * h2] = ev.x;
+            e[2 * h2 + 1] = ev.y;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            psum[ni] += e[q];
+            ev[mi][ni][g * 4 + q] = e[q];
+          }
+        }
+      }
+      const float tot = psum[ni] + __shfl_xor(psum[ni], 32);
+      if (half == 0) Pw[wm * FT + arow0 + 32 * ni + frow] = tot;
+    }
+    __syncthreads();
+    float *gS = p.fuse_s + (static_cast<size_t>(nt) * MT + mt) * FT;
+    if (tid < FT / 4) {
+      v4f_t s4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = 4 * tid + q;
+        s4[q] = (Pw[f] + Pw[FT + f]) + (Pw[2 * FT + f] + Pw[3 * FT + f]);
+      }
+      store_wt(gS + 4 * tid, s4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the S stores have left (inline-asm stores: nobody else waits for them)
+    __syncthreads();
+    uint32_t *cnt = p.fuse_cnt + 2 * nt;  // [arrived, left]; both zero between launches
+    if (tid == 0) {
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int ok = 1, spins = 0;
+      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < static_cast<uint32_t>(MT)) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > (1 << 20)) {  // ~1 s: something keeps this frame tile's other workgroups off the chip
+          ok = 0;
+          break;
+        }
+      }
+      ok_s[0] = ok;
+    }
+    __syncthreads();
+    const bool ok = ok_s[0] != 0;
+    if (ok) {
+      // all MT vectors of S, past the (non-coherent) L2: four 16-byte loads per lane in flight
+      const float *gall = p.fuse_s + static_cast<size_t>(nt) * MT * FT;
+      const int n4 = MT * FT / 4;
+      for (int i0 = tid; i0 < n4; i0 += 4 * Cfg::THREADS) {
+        const int i1 = min(i0 + Cfg::THREADS, n4 - 1), i2 = min(i0 + 2 * Cfg::THREADS, n4 - 1), i3 = min(i0 + 3 * Cfg::THREADS, n4 - 1);
+        v4f_t v0, v1, v2, v3;
+        asm volatile(
+            "global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+            "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+            : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+            : "v"(gall + 4 * static_cast<size_t>(i0)), "v"(gall + 4 * static_cast<size_t>(i1)), "v"(gall + 4 * static_cast<size_t>(i2)),
+              "v"(gall + 4 * static_cast<size_t>(i3))
+            : "memory");
+        *reinterpret_cast<v4f_t *>(Sg + 4 * i0) = v0;
+        *reinterpret_cast<v4f_t *>(Sg + 4 * i1) = v1;  // (clamped duplicates rewrite the same bytes)
+        *reinterpret_cast<v4f_t *>(Sg + 4 * i2) = v2;
+        *reinterpret_cast<v4f_t *>(Sg + 4 * i3) = v3;
+      }
+      for (int i = MT * FT + tid; i < L * FT; i += Cfg::THREADS) Sg[i] = 0.0f;  // zero padding: x + 0 = x
+      __syncthreads();
+      if (tid < FT) {  // adjacent pairs, level by level (normalize_row's tree), one frame per thread, in place
+        for (int len = L >> 1; len >= 1; len >>= 1)
+          for (int i = 0; i < len; ++i) Sg[i * FT + tid] = Sg[2 * i * FT + tid] + Sg[(2 * i + 1) * FT + tid];
+        inv_s[tid] = 1.0f / Sg[tid];  // p_i = e_i * RN(1 / total), as normalize_row
+      }
+    } else {
+      if (tid < FT) inv_s[tid] = 1.0f;
+      if (tid == 0) p.fuse_flag[static_cast<size_t>(nt) * MT + mt] = 1u;  // fuse_cleanup_kernel scales this tile
+    }
+    __syncthreads();
+    if (tid == 0) {  // the last workgroup to leave the frame tile resets its counters for the next launch
+      const uint32_t prev = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev == static_cast<uint32_t>(MT) - 1u) {
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    // phase 2: scale, transpose through the wave's LDS tile, 256-byte row segments out
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni) {
+      const float iv = inv_s[arow0 + 32 * ni + frow];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = ncol0 + 32 * mi + 8 * g + 4 * half;
+          *reinterpret_cast<v4f_t *>(wtile + frow * kOS + (nb - ncol0)) =
+              v4f_t{ev[mi][ni][g * 4 + 0] * iv, ev[mi][ni][g * 4 + 1] * iv, ev[mi][ni][g * 4 + 2] * iv, ev[mi][ni][g * 4 + 3] * iv};
+        }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int row = r * 4 + (lane >> 4), col = (lane & 15) * 4;
+        const v4f_t v = *reinterpret_cast<const v4f_t *>(wtile + row * kOS + col);
+        const int ff = fw0 + 32 * ni + row;
+        if (ff < p.n && ncol0 + col + 4 <= p.rows) store_wt(p.final + static_cast<size_t>(ff) * p.rows + ncol0 + col, v);
+      }
+    }
+    return;
+  }
   if (OUTPUT) {
     // CalculateOutput / LazyOutputActivations: z = sum/coef + bias (masked-out nodes keep
     // z = 0, dnn.cc:366-369), e = exp(z) (SoftMax::apply first loop, dnn.cc:536-540).
@@ -780,6 +939,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// Fused soft-max, the path nobody should ever see: a workgroup whose wait for its frame tile's other node tiles timed out
+// has stored exp(z) unscaled and raised its flag.  By the time this kernel runs every tile has published its row sums,
+// so the totals are complete: scale the flagged tile's block (one thread per frame), lower the flag.
+__global__ __launch_bounds__(64) void fuse_cleanup_kernel(QGemmParams p, int FT) {
+  const int MT = p.rows_pad / 256, tile = blockIdx.x, nt = tile / MT, mt = tile - nt * MT;
+  if (p.fuse_flag[tile] == 0u) return;
+  int L = 1;
+  while (L < MT) L <<= 1;
+  for (int f = threadIdx.x; f < FT; f += 64) {
+    const int frame = nt * FT + f;
+    if (frame >= p.n) continue;
+    float x[64];  // MT <= 32 on this path (qgemm_fused_ok)
+    for (int j = 0; j < 64; ++j) x[j] = j < MT ? p.fuse_s[(static_cast<size_t>(nt) * MT + j) * FT + f] : 0.0f;
+    for (int len = L >> 1; len >= 1; len >>= 1)
+      for (int i = 0; i < len; ++i) x[i] = x[2 * i] + x[2 * i + 1];
+    const float inv = 1.0f / x[0];
+    float *row = p.final + static_cast<size_t>(frame) * p.rows;
+    for (int c = mt * 256; c < min(p.rows, mt * 256 + 256); ++c) row[c] = row[c] * inv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) p.fuse_flag[tile] = 0u;
+}
+
 template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool FAST = true, int WM = 4>
 void launch_cfg(const QGemmParams &p, hipStream_t s) {
   using Cfg = GemmCfg<NF, WN, BK, STAGES, WM>;
@@ -791,6 +973,8 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
   auto k_masked = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT, false, WM>;
   auto k_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, false, OUTPUT, WM>;
   auto k_masked_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT, OUTPUT, WM>;
+  constexpr bool kCanFuse = OUTPUT && FAST && WM == 4 && WN == 2;
+  auto k_fused = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, false, false, WM, kCanFuse>;  // (= k_plain where it cannot)
   // the attribute is per device: a process may hold models on several GPUs
   static std::atomic<unsigned long long> attr_set{0};
   int dev = 0;
@@ -803,9 +987,15 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_masked), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_anyw), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_masked_anyw), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
-  if (p.tap_acc)
+  if (kCanFuse && p.fuse_s != nullptr) {
+    // fused soft-max: the node tiles of a frame tile are consecutive blocks; a second, near-empty launch scales whatever a
+    // workgroup that gave up waiting left unscaled (normally nothing: every workgroup reads one flag and leaves)
+    hipLaunchKernelGGL(k_fused, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+    hipLaunchKernelGGL(fuse_cleanup_kernel, dim3(MT * NT), dim3(64), 0, s, p, Cfg::FT);
+  } else if (p.tap_acc)
     hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else if (OUTPUT && p.mask == nullptr && (p.rows & 31) == 0)
     hipLaunchKernelGGL(k_plain, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
@@ -866,6 +1056,10 @@ void launch_qgemm(const QGemmParams &p, hipStream_t s) {
     // a CU of its own anyway (small batches: one latency-bound k-loop per launch) a 6-stage
     // ring hides twice the load latency per step
     case 128:
+      if (p.node_tile == 128) {  // 128 nodes x 128 frames, 2 x 2 waves, double-buffered 128-byte k-steps, two workgroups per CU
+        launch_cfg<2, 2, 128, 2, OUTPUT, true, 2>(p, s);
+        break;
+      }
       if (static_cast<long>(p.rows_pad / 256) * (p.n_pad / 128) <= 256 && !p.tap_acc) {
         if (small_bk == 128)
           launch_cfg<4, 1, 128, 3, OUTPUT>(p, s);
@@ -940,6 +1134,39 @@ bool qgemm_small_pick(int rows_pad, int K, int n, int fastdiv, bool output) {
   (void)rows_pad;
   const int lim = small_max >= 0 ? small_max : output ? 512 : 640;
   return n <= lim && qgemm_small_ok(K, fastdiv);
+}
+
+// Mid-size batches of the hidden layers: when the layer is between one and two rounds of 128 x 128 tiles (2 049 .. 4 096
+// frames on a 2048-node layer), the four-wave 128 x 128 shape -- two workgroups per CU, so one's prologue / epilogue
+// hides under the other's k-loop -- beats the 256-node tiles of the same area (tools/batch_sweep.py, six hidden layers:
+// 140 vs 158 us at 2 560 frames, 141 vs 158 at 3 000, 151 vs 162 at 4 000; it loses below (123 vs 119 at 2 000: one
+// workgroup per CU again) and above (229 vs 202 at 5 000), and on the 8000-node output layer).  Returns 128 or 256;
+// with 128 the frame tile is 128 as well.
+bool qgemm_fused_ok(const QGemmParams &p) {
+  static const bool off = [] {
+    const char *e = std::getenv("FDNN_FUSE_NORM");
+    return e && std::atoi(e) == 0;
+  }();
+  if (off || p.small || !p.fastdiv || p.mask || p.tap_acc || p.tap_logit || (p.rows & 31) != 0) return false;
+  if (p.frame_tile != 320 && p.frame_tile != 256) return false;
+  const int MT = p.rows_pad / 256;
+  int L = 1;
+  while (L < MT) L <<= 1;
+  // the epilogue's LDS: eight wave tiles, then 4 partial rows + the inverses + L rows of S, below the table / bias area
+  const long need = 8192 + 8 * 32 * 68 * 4 + (5L * p.frame_tile + 4 + static_cast<long>(L) * p.frame_tile) * 4;
+  const long have = static_cast<long>(256 + p.frame_tile) * 128 * 2;  // GemmCfg<.., 128, 2>::FIX_OFF
+  return L <= 32 && need <= have;
+}
+
+int qgemm_node_tile(int rows_pad, int n, bool output) {
+  static const int forced = [] {
+    const char *e = std::getenv("FDNN_NODE_TILE");
+    return e ? std::atoi(e) : 0;
+  }();
+  if (forced == 128 || forced == 256) return forced;
+  if (output) return 256;
+  const long tiles = static_cast<long>(rows_pad / 128) * ((n + 127) / 128);
+  return (tiles > 256 && tiles <= 512) ? 128 : 256;
 }
 
 void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s) {

@@ -81,6 +81,9 @@ struct fdnn_ctx {
   float *d_out = nullptr;         // [n][O]
   float *d_partial = nullptr;     // [rows_pad/64][n_pad]
   int8_t *d_mask = nullptr;       // [n][O]
+  float *d_fuse_s = nullptr;        // fused soft-max: per-tile row sums [n_pad / tile][rows_pad / 256][tile] floats
+  uint32_t *d_fuse_cnt = nullptr;   // {arrived, left} per frame tile; zero between launches
+  uint32_t *d_fuse_flag = nullptr;  // per tile: "gave up waiting" (fuse_cleanup_kernel); zero between launches
   uint64_t *d_mask_bits = nullptr;  // [n][ceil(O/64)] the batched lazy call's mask as bits (launch_mask_pack)
   int last = -1;                  // d_act index holding the last hidden layer, -1 = not computed
   bool pooled = false;
@@ -120,6 +123,9 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps);
 // HBM-bound scale pass can run under the next batch's layer 0.
 int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out, hipStream_t s, const Taps *taps,
                float *d_final = nullptr, hipStream_t tail = nullptr, hipEvent_t gemm_done = nullptr);
+// Will run_output scale the soft-max inside the output kernel for such a call (dense, large batch)?  Then there is no
+// scale pass to hide under the next batch's layer 0.
+bool output_will_fuse(fdnn_ctx *c, int count, const int8_t *d_masks);
 // A dense pass over a very large batch runs as chunks of kChunkFrames frames (32 frame tiles of 320: one
 // workgroup per CU in the hidden layers): a chunk's 320 MB of exp(z) rows are written and re-read by its soft-max
 // scale within a working set the 256 MB Infinity Cache and the translation caches largely cover, which a

@@ -20,17 +20,44 @@ namespace {
 #define FDNN_NORM_BG_NT 1  // non-temporal loads / stores in the background scale kernel: its 640 MB stream through the
                            // L2s that layer 0 (running beside it) keeps its operand images in; +2 % on the overlapped step
 #endif
+constexpr int kNormMaxTiles = 2048;  // 256-node tiles a row total can span (output layers up to 524 288 nodes)
 template <bool NT>
 __device__ __forceinline__ void normalize_row(const float *out, float *dst, const float *partial, int f, int partial_ld, int rows,
                                               int n_partial, float *red) {
   const int tid = threadIdx.x;
-  float s = 0.0f;
-  for (int t = tid; t < n_partial; t += 256) s += partial[static_cast<size_t>(t) * partial_ld + f];
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-  if ((tid & 63) == 0) red[tid >> 6] = s;
+  // The row total, in THE order every path of this library uses (fdnn_device.hpp: softmax_total_order): the four
+  // 64-node partial sums of each 256-node tile first, S_j = (P[4j] + P[4j+1]) + (P[4j+2] + P[4j+3]), then the S_j by
+  // adjacent pairs, level by level (zero-padded to a power of two: x + 0 = x).  The large-batch output kernel computes
+  // the same tree inside its epilogue (the 256-node tile is its workgroup), which is what lets it write probabilities
+  // directly instead of exp(z) for this pass to scale.
+  const int MT = n_partial >> 2;  // n_partial = rows_pad / 64, rows_pad a multiple of 256
+  int L = 1;
+  while (L < MT) L <<= 1;
+  for (int t = tid; t < L; t += 256) {
+    float sj = 0.0f;
+    if (t < MT) {
+      const float *pp = partial + static_cast<size_t>(4 * t) * partial_ld + f;
+      sj = (pp[0] + pp[partial_ld]) + (pp[2 * static_cast<size_t>(partial_ld)] + pp[3 * static_cast<size_t>(partial_ld)]);
+    }
+    red[t] = sj;
+  }
   __syncthreads();
-  const float total = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int len = L >> 1; len >= 1; len >>= 1) {
+    float v[kNormMaxTiles / 256];
+#pragma unroll
+    for (int q = 0; q < kNormMaxTiles / 256; ++q) {
+      const int t = tid + 256 * q;
+      v[q] = t < len ? red[2 * t] + red[2 * t + 1] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kNormMaxTiles / 256; ++q) {
+      const int t = tid + 256 * q;
+      if (t < len) red[t] = v[q];
+    }
+    __syncthreads();
+  }
+  const float total = red[0];
   // p_i = e_i / total (dnn.cc:541-543) as e_i * RN(1 / total): within one ulp of the quotient
   // (1.2e-7 relative; the hardware exp already differs from glibc's expf by more), and one
   // multiply per element instead of the ~10-instruction IEEE division sequence -- which does not
@@ -82,7 +109,7 @@ __device__ __forceinline__ void normalize_row(const float *out, float *dst, cons
 
 __global__ __launch_bounds__(256) void normalize_kernel(const float *out, float *dst, const float *partial, int n, int partial_ld,
                                                         int rows, int n_partial) {
-  __shared__ float red[4];
+  __shared__ float red[kNormMaxTiles];
 #ifndef FDNN_NORM_NT
 #define FDNN_NORM_NT 0  // non-temporal here too (same box, tools/kstat.py): this pass 105 -> 118 us, the kernels after it
                         // (whose operands it no longer evicts) -12 us together -- nothing in it
@@ -98,7 +125,7 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float *out, float 
 // starved until the scale pass was done (rocprofv3 timeline: 120 us overlap, layer 0 330 -> 430 us).
 __global__ __launch_bounds__(256) void normalize_bg_kernel(const float *out, float *dst, const float *partial, int n,
                                                            int partial_ld, int rows, int n_partial) {
-  __shared__ float red[4];
+  __shared__ float red[kNormMaxTiles];
   for (int f = blockIdx.x; f < n; f += gridDim.x) {
     normalize_row<(FDNN_NORM_BG_NT != 0)>(out, dst, partial, f, partial_ld, rows, n_partial, red);
     __syncthreads();  // red[] is reused by the next row

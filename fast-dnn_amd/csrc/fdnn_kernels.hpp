@@ -47,6 +47,7 @@ void launch_l0_weight_image(const float *w, float *wt, int H, int D, int j_pad, 
 // Frame tile (32/64/128/160/256/320) the int8 GEMM should use for `n` frames of a layer
 // with rows_pad padded nodes; n_pad = n rounded up to it.
 int qgemm_frame_tile(int rows_pad, int n);
+int qgemm_node_tile(int rows_pad, int n, bool output);  // 256, or 128 where the 128 x 128 shape (frame tile 128) is the better one
 int qgemm_debug_flags();
 
 // int8 layer: C[node][frame] = sum_k W[node][k] * (A[frame][k] + 128), then the
@@ -64,6 +65,7 @@ struct QGemmParams {
   int ldw, lda;           // row strides (bytes) of w and a: K plus the anti-channel-conflict skew
   int frame_tile;         // 32 / 64 / 128 / 160 / 256 / 320, n_pad is a multiple of it
   int small;              // 1: the small-batch kernel (fdnn_small.hip; frame_tile = 32)
+  int node_tile;          // 256 (default) or 128: with frame_tile 128, the 128 x 128 four-wave shape for mid-size batches
   int debug;              // timing experiments only (FDNN_GEMM_DEBUG): 1 no staging, 2 no MFMA, 4 no LDS reads
   float coef, rcp_coef;
   int fastdiv;
@@ -77,6 +79,13 @@ struct QGemmParams {
   const int8_t *mask;     // [n][rows] or null (lazy contract)
   const uint64_t *mask_bits;  // [n][mask_wpr] the same mask, one bit per node (launch_mask_pack), or null: the large-batch
   int mask_wpr;               // production instances read one 64-bit word per frame row and 64-node group instead of 64 bytes
+  // fused soft-max (large-batch dense output instance): where the probabilities go, the per-tile row sums S
+  // [n_pad / frame_tile][rows_pad / 256][frame_tile], the per-frame-tile {arrived, left} counters (zero between launches)
+  // and the per-tile "gave up waiting" flags for fuse_cleanup_kernel; all null = the unfused path
+  float *final;
+  float *fuse_s;
+  uint32_t *fuse_cnt;
+  uint32_t *fuse_flag;
   // accumulator probe of the PRODUCTION output instances (parity tests only; null otherwise): the int32 accumulators of
   // every probe_stride-th frame, [ceil(n / probe_stride)][rows] -- a wave-uniform branch in front of the epilogue
   int32_t *acc_probe;
@@ -91,6 +100,9 @@ bool qgemm_small_ok(int K, int fastdiv);
 bool qgemm_small_pick(int rows_pad, int K, int n, int fastdiv, bool output);
 void launch_qgemm_small_hidden(const QGemmParams &p, hipStream_t s);
 void launch_qgemm_small_output(const QGemmParams &p, hipStream_t s);
+// Fused soft-max available for this launch?  (dense production call, 8-wave shapes, the row sums of all node tiles fit the
+// epilogue's LDS)
+bool qgemm_fused_ok(const QGemmParams &p);
 void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s);
 void launch_qgemm_output(const QGemmParams &p, hipStream_t s);
 

@@ -312,7 +312,7 @@ int load_host_model(const std::string &path, float cutoff, HostModel *out, std::
     RawLayer &L = layers[size_t(j)];
     L.in_dim = c.i32();
     L.out_dim = c.i32();
-    if (!c.ok || L.in_dim <= 0 || L.out_dim <= 0 || L.in_dim > (1 << 20) || L.out_dim > (1 << 24)) {
+    if (!c.ok || L.in_dim <= 0 || L.out_dim <= 0 || L.in_dim > (1 << 20) || L.out_dim > (1 << 19)) {  // (2^19 output nodes = 2048 soft-max tiles of 256: normalize_row's tree)
       *msg = "bad layer header at layer " + std::to_string(j);
       return FDNN_E_FORMAT;
     }
@@ -371,7 +371,7 @@ int adopt_blob(std::vector<uint8_t> &&bytes, HostModel *out, std::string *msg) {
     return FDNN_E_FORMAT;
   };
   if (h.n_affine != h.n_q + 1 || h.in_dim <= 0 || h.in_dim % 4 || h.hidden <= 0 || h.hidden % 16 || h.out_dim <= 0 ||
-      h.in_dim > (1 << 20) || h.hidden > 32768)
+      h.in_dim > (1 << 20) || h.hidden > 32768 || h.out_dim > (1 << 19))
     return bad("inconsistent dimensions");
   const uint64_t H = uint64_t(h.hidden), D = uint64_t(h.in_dim);
   if (!inside(h.off_w0, 4 * H * D) || !inside(h.off_b0, 4 * H) || !inside(h.off_shift, 4 * D) || !inside(h.off_scale, 4 * D) ||

@@ -140,6 +140,9 @@ void destroy_ctx(fdnn_ctx *c) {
   hipFree(c->d_partial);
   hipFree(c->d_mask);
   hipFree(c->d_mask_bits);
+  hipFree(c->d_fuse_s);
+  hipFree(c->d_fuse_cnt);
+  hipFree(c->d_fuse_flag);
   if (c->h_mask_pin) hipHostFree(c->h_mask_pin);
   if (c->h_out_pin) hipHostFree(c->h_out_pin);
   if (c->done) hipEventDestroy(c->done);
@@ -185,6 +188,14 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
   alloc(reinterpret_cast<void **>(&c->d_partial), sizeof(float) * npt * (max_rows_pad / fdnn::kPartialNodes));
   if (!lean) alloc(reinterpret_cast<void **>(&c->d_mask), np * h.out_dim);
   alloc(reinterpret_cast<void **>(&c->d_mask_bits), sizeof(uint64_t) * np * size_t((h.out_dim + 63) / 64));
+  {  // fused soft-max (large dense batches): row sums per 256-node tile, counters and flags per tile (kept zero between launches)
+    const size_t mt = size_t(max_rows_pad / 256), tiles = (npt + 255) / 256 + 1;
+    alloc(reinterpret_cast<void **>(&c->d_fuse_s), sizeof(float) * npt * mt);
+    alloc(reinterpret_cast<void **>(&c->d_fuse_cnt), sizeof(uint32_t) * 2 * tiles);
+    alloc(reinterpret_cast<void **>(&c->d_fuse_flag), sizeof(uint32_t) * tiles * mt);
+    if (e == hipSuccess) e = hipMemset(c->d_fuse_cnt, 0, sizeof(uint32_t) * 2 * tiles);
+    if (e == hipSuccess) e = hipMemset(c->d_fuse_flag, 0, sizeof(uint32_t) * tiles * mt);
+  }
   if (e == hipSuccess && !lean)  // at least one padded row: the one-frame kernel reads the mask in 16-byte pieces up to rows_pad
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mask_pin), std::max(size_t(kPinFrames) * h.out_dim, size_t(max_rows_pad)), hipHostMallocMapped);
   if (e == hipSuccess && !lean) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_mask_pin), c->h_mask_pin, 0);
@@ -246,6 +257,8 @@ fdnn::QGemmParams prepare_qlayer(fdnn_ctx *c, const QLayerDesc &d, const int8_t 
   fdnn::QGemmParams g{};
   g.small = fdnn::qgemm_small_pick(d.rows_pad, d.cols_pad - fdnn::kRowSkew, n, d.fastdiv_ok, output) ? 1 : 0;
   g.frame_tile = g.small ? 32 : d.fastdiv_ok ? fdnn::qgemm_frame_tile(d.rows_pad, n) : 128;  // the true-divide kernel has one shape
+  g.node_tile = (!g.small && d.fastdiv_ok) ? fdnn::qgemm_node_tile(d.rows_pad, n, output) : 256;
+  if (g.node_tile == 128) g.frame_tile = 128;
   g.debug = fdnn::qgemm_debug_flags();
   g.n = n;
   g.n_pad = round_up(n, g.frame_tile);
@@ -361,23 +374,38 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   g.tap_logit = taps ? taps->logits : nullptr;
   g.acc_probe = taps ? taps->acc_probe : nullptr;
   g.probe_stride = taps ? std::max(1, taps->probe_stride) : 1;
+  const bool fused = fdnn::qgemm_fused_ok(g);  // (taps exclude it; the accumulator probe of the parity tests does not)
+  if (fused) {
+    g.final = d_final ? d_final : d_out;
+    g.fuse_s = c->d_fuse_s;
+    g.fuse_cnt = c->d_fuse_cnt;
+    g.fuse_flag = c->d_fuse_flag;
+  }
   {
     ProfScope ps(m, s, FDNN_PROF_OUTPUT);
     fdnn::launch_qgemm_output(g, s);
   }
   hipStream_t ns = s;
-  if (tail && gemm_done) {  // the scale pass goes to the tail stream, behind the GEMM
-    HIP_TRY(hipEventRecord(gemm_done, s));
+  if (tail && gemm_done) {  // the scale pass goes to the tail stream, behind the GEMM (fused: nothing is left to run
+    HIP_TRY(hipEventRecord(gemm_done, s));  // there, but the caller records its completion event on the tail stream)
     HIP_TRY(hipStreamWaitEvent(tail, gemm_done, 0));
     ns = tail;
   }
-  {
+  if (!fused) {
     ProfScope ps(m, ns, FDNN_PROF_NORMALIZE);
     fdnn::launch_normalize(d_out, d_final ? d_final : d_out, c->d_partial, count, g.partial_ld, d.rows, d.rows_pad / fdnn::kPartialNodes, ns,
                            ns != s);
   }
   HIP_TRY(hipGetLastError());
   return FDNN_OK;
+}
+
+bool output_will_fuse(fdnn_ctx *c, int count, const int8_t *d_masks) {
+  const BlobHeader &h = c->m->hm.hdr;
+  const QLayerDesc &d = h.q[h.n_q - 1];
+  fdnn::QGemmParams g = prepare_qlayer(c, d, c->d_act[0], count, nullptr, true);
+  g.mask = d_masks;
+  return fdnn::qgemm_fused_ok(g);
 }
 
 // Device -> pageable host memory for large results (the 8000-float rows of a whole batch:

@@ -148,7 +148,11 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
     const char *e = std::getenv("FDNN_SERVER_OVERLAP");
     return e ? std::atoi(e) != 0 : true;
   }();
-  c->l0_chain_only = !small && overlap;  // see fdnn_ctx: the overlapped scale pass needs room beside layer 0
+  // (a dense large batch scales its soft-max inside the output kernel: no pass to overlap, layer 0 takes the faster
+  // screened path; the chain kernel + background scale pass remain for lazy batches)
+  const int chunk_n = small ? n : fdnn::frame_chunks(n).front().second;
+  const bool fused = !small && fdnn::output_will_fuse(c, chunk_n, d_masks);
+  c->l0_chain_only = !small && overlap && !fused;  // see fdnn_ctx: the overlapped scale pass needs room beside layer 0
   hipStream_t cs = small ? sl.stream : s->s_main;
   if (after) HIP_TRY(hipStreamWaitEvent(cs, after, 0));
   HIP_TRY(fdnn::ctx_enter(c, cs));

@@ -298,3 +298,26 @@ def test_production_output_instance_accumulators_are_bit_exact(net_model_path, n
     want, wt = Oracle(net_model_path).calculate(x[idx], taps=True)
     assert np.array_equal(acc, wt["acc_out"]), np.argwhere(acc != wt["acc_out"])[:5].tolist()
     assert np.abs(probs[idx] - want).max() <= 2e-6
+
+
+@pytest.mark.parametrize("n", [2100, 3000, 4096])
+def test_mid_size_batches_on_the_128_node_shape(net_model_path, n):
+    """2 049 .. 4 096 frames on the 2048-node layers take the four-wave 128-node x 128-frame tile (two workgroups per CU:
+    qgemm_kernel<2,2,128,2,..,WM=2>), the 8000-node output layer the 256-node tiles.  Eight frames of every 128-frame
+    tile: last hidden layer bit for bit against the oracle, soft-max rows to 2e-6; the production output instance's
+    int32 accumulators of every 64th frame bit for bit."""
+    x = F.synth_features(n, 432, seed=300 + n)
+    idx = sample_every_tile(n, 128, 8, seed=2)
+    orc = Oracle(net_model_path)
+    want, wt = orc.calculate(x[idx], taps=True)
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    ctx = dnn.getNewLazyContext(n)
+    ctx.calculateUntilOutput(x)
+    hid = ctx.hiddenActivations()
+    ctx.delete()
+    assert (hid[idx] == wt["u8_acts"][-1]).all()
+    acc, p = dnn.productionOutputAcc(x, 64, probs=True)
+    dnn.delete()
+    assert np.abs(p[idx] - want).max() <= TIGHT
+    _, wt64 = orc.calculate(x[::64], taps=True)
+    assert np.array_equal(acc, wt64["acc_out"])
