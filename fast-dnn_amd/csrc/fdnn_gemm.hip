@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     }
   }
   if constexpr (FUSED) {
-    static_assert(!FUSED || (OUTPUT && PLAIN && FAST && !MASKED && !ANYW && !TAP && WM == 4), "fused soft-max: the dense production instance only");
+    static_assert(!FUSED || (OUTPUT && PLAIN && FAST && !ANYW && !TAP && WM == 4), "fused soft-max: the dense / batched-lazy production instances only");
     // ---------------------------------------------------------------- fused soft-max
     // SoftMax::apply (dnn.cc:534-544) inside the output kernel.  Phase 1: e = exp(z) replaces each accumulator IN
     // PLACE (160 registers per lane stay live), the 64-node partial sums P are formed exactly as in the unfused
@@ -548,6 +548,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     while (L < MT) L <<= 1;
     // (the host launches this instance only when kFuseOff + (5 FT + 4 + L FT) * 4 <= Cfg::FIX_OFF)
     float ev[2][NF][16];  // exp(z): takes over the accumulators' registers as they die
+    // MASKED (batched lazy call): one 64-bit word of mask bits per frame row covers this wave's 64 nodes (launch_mask_pack)
+    uint64_t fmw[NF];
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni) {
+      const int ff = fw0 + 32 * ni + frow, grp = ncol0 >> 6;
+      fmw[ni] = (MASKED && ff < p.n && grp < p.mask_wpr) ? p.mask_bits[static_cast<size_t>(ff) * p.mask_wpr + grp] : 0ull;
+    }
 #pragma unroll
     for (int ni = 0; ni < NF; ++ni) {
 #pragma unroll
@@ -567,11 +574,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
             const v2f_e x = {static_cast<float>(acc[mi][ni][g * 4 + 2 * h2]), static_cast<float>(acc[mi][ni][g * 4 + 2 * h2 + 1])};
             const v2f_e q0 = x * rcp2;
             const v2f_e r = __builtin_elementwise_fma(-q0, coef2, x);
-            const v2f_e z = __builtin_elementwise_fma(r, rcp2, q0) + v2f_e{bj[2 * h2], bj[2 * h2 + 1]};
+            v2f_e z = __builtin_elementwise_fma(r, rcp2, q0) + v2f_e{bj[2 * h2], bj[2 * h2 + 1]};
+            if (MASKED) {  // masked-out nodes keep z = 0 (dnn.cc:366-369)
+              const uint32_t nib = static_cast<uint32_t>(fmw[ni] >> (32 * mi + 8 * g + 4 * half)) & 0xfu;
+              if (((nib >> (2 * h2)) & 1u) == 0) z.x = 0.0f;
+              if (((nib >> (2 * h2 + 1)) & 1u) == 0) z.y = 0.0f;
+            }
             const v2f_e y = z * log2e2;
-            const v2f_e ev = v2f_e{__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)} * v2f_e{in4 ? 1.0f : 0.0f, in4 ? 1.0f : 0.0f};
-            e[2 * h2] = ev.x;
-            e[2 * h2 + 1] = ev.y;
+            const v2f_e ex = v2f_e{__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)} * v2f_e{in4 ? 1.0f : 0.0f, in4 ? 1.0f : 0.0f};
+            e[2 * h2] = ex.x;
+            e[2 * h2 + 1] = ex.y;
           }
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -602,7 +614,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
       int ok = 1, spins = 0;
       while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < static_cast<uint32_t>(MT)) {
         __builtin_amdgcn_s_sleep(16);
-        if (++spins > (1 << 20)) {  // ~1 s: something keeps this frame tile's other workgroups off the chip
+        if (++spins > (1 << 15)) {  // tens of milliseconds (a legitimate wait is microseconds): something keeps this frame tile's other workgroups off the chip
           ok = 0;
           break;
         }
@@ -975,6 +987,7 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
   auto k_masked_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT, OUTPUT, WM>;
   constexpr bool kCanFuse = OUTPUT && FAST && WM == 4 && WN == 2;
   auto k_fused = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, false, false, WM, kCanFuse>;  // (= k_plain where it cannot)
+  auto k_fused_masked = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, kCanFuse, false, WM, kCanFuse>;
   // the attribute is per device: a process may hold models on several GPUs
   static std::atomic<unsigned long long> attr_set{0};
   int dev = 0;
@@ -988,12 +1001,13 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_anyw), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_masked_anyw), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_masked), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
   if (kCanFuse && p.fuse_s != nullptr) {
     // fused soft-max: the node tiles of a frame tile are consecutive blocks; a second, near-empty launch scales whatever a
     // workgroup that gave up waiting left unscaled (normally nothing: every workgroup reads one flag and leaves)
-    hipLaunchKernelGGL(k_fused, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+    hipLaunchKernelGGL(p.mask ? k_fused_masked : k_fused, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
     hipLaunchKernelGGL(fuse_cleanup_kernel, dim3(MT * NT), dim3(64), 0, s, p, Cfg::FT);
   } else if (p.tap_acc)
     hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
@@ -1147,7 +1161,7 @@ bool qgemm_fused_ok(const QGemmParams &p) {
     const char *e = std::getenv("FDNN_FUSE_NORM");
     return e && std::atoi(e) == 0;
   }();
-  if (off || p.small || !p.fastdiv || p.mask || p.tap_acc || p.tap_logit || (p.rows & 31) != 0) return false;
+  if (off || p.small || !p.fastdiv || (p.mask && !p.mask_bits) || p.tap_acc || p.tap_logit || (p.rows & 31) != 0) return false;
   if (p.frame_tile != 320 && p.frame_tile != 256) return false;
   const int MT = p.rows_pad / 256;
   int L = 1;

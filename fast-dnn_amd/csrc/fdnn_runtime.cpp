@@ -405,6 +405,7 @@ bool output_will_fuse(fdnn_ctx *c, int count, const int8_t *d_masks) {
   const QLayerDesc &d = h.q[h.n_q - 1];
   fdnn::QGemmParams g = prepare_qlayer(c, d, c->d_act[0], count, nullptr, true);
   g.mask = d_masks;
+  if (d_masks && !g.small) g.mask_bits = c->d_mask_bits;  // (what run_output will do)
   return fdnn::qgemm_fused_ok(g);
 }
 
