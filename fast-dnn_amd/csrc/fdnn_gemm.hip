@@ -596,6 +596,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
       if (half == 0) Pw[wm * FT + arow0 + 32 * ni + frow] = tot;
     }
     __syncthreads();
+#if FDNN_GEMM_DEBUG & 64
+    long long tf[6];
+    tf[0] = __builtin_readcyclecounter();
+#endif
     float *gS = p.fuse_s + (static_cast<size_t>(nt) * MT + mt) * FT;
     if (tid < FT / 4) {
       v4f_t s4;
@@ -608,11 +612,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the S stores have left (inline-asm stores: nobody else waits for them)
     __syncthreads();
+#if FDNN_GEMM_DEBUG & 64
+    tf[1] = __builtin_readcyclecounter();
+#endif
     uint32_t *cnt = p.fuse_cnt + 2 * nt;  // [arrived, left]; both zero between launches
     if (tid == 0) {
       __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int ok = 1, spins = 0;
-      while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < static_cast<uint32_t>(MT)) {
+      int ok = (p.debug & 4096) && mt % 3 == 0 ? 0 : 1, spins = 0;  // FDNN_GEMM_DEBUG=4096 (tests): every third node tile "gives up"
+      while (ok && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < static_cast<uint32_t>(MT)) {
         __builtin_amdgcn_s_sleep(16);
         if (++spins > (1 << 15)) {  // tens of milliseconds (a legitimate wait is microseconds): something keeps this frame tile's other workgroups off the chip
           ok = 0;
@@ -623,24 +630,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     }
     __syncthreads();
     const bool ok = ok_s[0] != 0;
+#if FDNN_GEMM_DEBUG & 64
+    tf[2] = __builtin_readcyclecounter();
+#endif
     if (ok) {
       // all MT vectors of S, past the (non-coherent) L2: four 16-byte loads per lane in flight
       const float *gall = p.fuse_s + static_cast<size_t>(nt) * MT * FT;
       const int n4 = MT * FT / 4;
-      for (int i0 = tid; i0 < n4; i0 += 4 * Cfg::THREADS) {
-        const int i1 = min(i0 + Cfg::THREADS, n4 - 1), i2 = min(i0 + 2 * Cfg::THREADS, n4 - 1), i3 = min(i0 + 3 * Cfg::THREADS, n4 - 1);
-        v4f_t v0, v1, v2, v3;
+      for (int i0 = tid; i0 < n4; i0 += 8 * Cfg::THREADS) {  // eight 16-byte loads per lane in flight: one round trip for MT = 32
+        int ix[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ix[u] = min(i0 + u * Cfg::THREADS, n4 - 1);  // (clamped duplicates rewrite the same bytes)
+        v4f_t v0, v1, v2, v3, v4, v5, v6, v7;
         asm volatile(
-            "global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
-            "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-            : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
-            : "v"(gall + 4 * static_cast<size_t>(i0)), "v"(gall + 4 * static_cast<size_t>(i1)), "v"(gall + 4 * static_cast<size_t>(i2)),
-              "v"(gall + 4 * static_cast<size_t>(i3))
+            "global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\t"
+            "global_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\t"
+            "global_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\t"
+            "global_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+            : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+            : "v"(gall + 4 * static_cast<size_t>(ix[0])), "v"(gall + 4 * static_cast<size_t>(ix[1])), "v"(gall + 4 * static_cast<size_t>(ix[2])),
+              "v"(gall + 4 * static_cast<size_t>(ix[3])), "v"(gall + 4 * static_cast<size_t>(ix[4])), "v"(gall + 4 * static_cast<size_t>(ix[5])),
+              "v"(gall + 4 * static_cast<size_t>(ix[6])), "v"(gall + 4 * static_cast<size_t>(ix[7]))
             : "memory");
-        *reinterpret_cast<v4f_t *>(Sg + 4 * i0) = v0;
-        *reinterpret_cast<v4f_t *>(Sg + 4 * i1) = v1;  // (clamped duplicates rewrite the same bytes)
-        *reinterpret_cast<v4f_t *>(Sg + 4 * i2) = v2;
-        *reinterpret_cast<v4f_t *>(Sg + 4 * i3) = v3;
+        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[0]) = v0;
+        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[1]) = v1;
+        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[2]) = v2;
+        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[3]) = v3;
+        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[4]) = v4;
+        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[5]) = v5;
+        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[6]) = v6;
+        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[7]) = v7;
       }
       for (int i = MT * FT + tid; i < L * FT; i += Cfg::THREADS) Sg[i] = 0.0f;  // zero padding: x + 0 = x
       __syncthreads();
@@ -661,6 +680,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
         __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
+#if FDNN_GEMM_DEBUG & 64
+    tf[3] = __builtin_readcyclecounter();
+#endif
     // phase 2: scale, transpose through the wave's LDS tile, 256-byte row segments out
 #pragma unroll
     for (int ni = 0; ni < NF; ++ni) {
@@ -678,9 +700,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
         const int row = r * 4 + (lane >> 4), col = (lane & 15) * 4;
         const v4f_t v = *reinterpret_cast<const v4f_t *>(wtile + row * kOS + col);
         const int ff = fw0 + 32 * ni + row;
+#ifdef FDNN_FUSE_PLAIN_STORE
+        if (ff < p.n && ncol0 + col + 4 <= p.rows) *reinterpret_cast<v4f_t *>(p.final + static_cast<size_t>(ff) * p.rows + ncol0 + col) = v;
+#elif defined(FDNN_FUSE_NT_STORE)
+        if (ff < p.n && ncol0 + col + 4 <= p.rows) __builtin_nontemporal_store(v, reinterpret_cast<v4f_t *>(p.final + static_cast<size_t>(ff) * p.rows + ncol0 + col));
+#else
         if (ff < p.n && ncol0 + col + 4 <= p.rows) store_wt(p.final + static_cast<size_t>(ff) * p.rows + ncol0 + col, v);
+#endif
       }
     }
+#if FDNN_GEMM_DEBUG & 64
+    tf[4] = __builtin_readcyclecounter();
+    if (tid == 0 && (blockIdx.x % 149) == 0)
+      printf("FUSED %4d: prologue %lld first-stage %lld mainloop %lld | exp %lld publish %lld wait %lld gather+tree %lld scale+store %lld | total %lld\n", blockIdx.x,
+             ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], tf[0] - ts[3], tf[1] - tf[0], tf[2] - tf[1], tf[3] - tf[2], tf[4] - tf[3], tf[4] - ts[0]);
+#endif
     return;
   }
   if (OUTPUT) {

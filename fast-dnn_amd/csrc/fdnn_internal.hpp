@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -53,6 +54,11 @@ struct fdnn_model {
   std::vector<fdnn_ctx *> pool;  // idle contexts owned by the model (fdnn_calculate*)
   struct fdnn_server *batcher = nullptr;  // fdnn_model_enable_batcher: fdnn_calculate goes through it
   struct fdnn_group *group = nullptr;     // fdnn_group_attach: this model leads a device group, fdnn_calculate shards over it
+  // Host-pointer calls in flight on this model (fdnn_calculate from many threads, each on its own stream).  The fused
+  // soft-max's workgroups wait for their frame tile's other node tiles; many such kernels on the chip at once can hold
+  // each other's CUs (nine partially dispatched frame tiles fill 256 CUs), which would send them all through the
+  // give-up path: beyond kMaxFusedCallers concurrent callers a call takes the unfused output kernel + scale pass.
+  std::atomic<int> host_calls{0};
   // per-kernel HIP-event timing (fdnn_profile_begin/end); off in production
   bool profiling = false;
   struct ProfRec {
@@ -87,6 +93,7 @@ struct fdnn_ctx {
   uint64_t *d_mask_bits = nullptr;  // [n][ceil(O/64)] the batched lazy call's mask as bits (launch_mask_pack)
   int last = -1;                  // d_act index holding the last hidden layer, -1 = not computed
   bool pooled = false;
+  bool no_fuse = false;           // this call must not use the fused soft-max (too many concurrent host callers)
   bool l0_chain_only = false;     // scoring loop, large batches: the soft-max scale of the previous batch runs under this
                                   // batch's layer 0, which must then be the vector-pipe chain kernel (the matrix-pipe
                                   // screened path fills the register file: nothing can run beside it)
@@ -97,6 +104,7 @@ struct fdnn_ctx {
   float *h_out_pin = nullptr, *d_out_pin = nullptr;
 };
 constexpr int kPinFrames = 8;
+constexpr int kMaxFusedCallers = 4;
 
 
 namespace fdnn {

@@ -374,7 +374,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   g.tap_logit = taps ? taps->logits : nullptr;
   g.acc_probe = taps ? taps->acc_probe : nullptr;
   g.probe_stride = taps ? std::max(1, taps->probe_stride) : 1;
-  const bool fused = fdnn::qgemm_fused_ok(g);  // (taps exclude it; the accumulator probe of the parity tests does not)
+  const bool fused = !c->no_fuse && fdnn::qgemm_fused_ok(g);  // (taps exclude it; the accumulator probe of the parity tests does not)
   if (fused) {
     g.final = d_final ? d_final : d_out;
     g.fuse_s = c->d_fuse_s;
@@ -544,11 +544,14 @@ int calculate_on_one_device(fdnn_model *m, const float *x, int n, int dim, int b
   hipError_t e = hipStreamWaitEvent(s, c->done, 0);
   if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x, sizeof(float) * size_t(n) * dim, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
+    c->no_fuse = m->host_calls.fetch_add(1, std::memory_order_relaxed) >= kMaxFusedCallers;  // (see fdnn_model::host_calls)
     rc = run_hidden(c, c->d_x, s, nullptr);
     if (!rc) rc = run_output(c, 0, n, nullptr, c->d_out, s, nullptr);
     if (!rc) rc = copy_out(out, c->d_out, sizeof(float) * size_t(n) * h.out_dim, s);
+    if (rc) hipStreamSynchronize(s);
+    m->host_calls.fetch_sub(1, std::memory_order_relaxed);  // the stream is idle again here
+    c->no_fuse = false;
   }
-  if (e == hipSuccess && rc) hipStreamSynchronize(s);
   release_ctx(c, s);
   if (rc) return rc;
   if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("fdnn_calculate: ") + hipGetErrorString(e));

@@ -321,3 +321,34 @@ def test_mid_size_batches_on_the_128_node_shape(net_model_path, n):
     assert np.abs(p[idx] - want).max() <= TIGHT
     _, wt64 = orc.calculate(x[::64], taps=True)
     assert np.array_equal(acc, wt64["acc_out"])
+
+
+def test_fused_softmax_equals_the_scale_pass_and_its_give_up_path(net_model_path, tmp_path):
+    """Large dense batches scale the soft-max inside the output kernel (fused: exp(z) stays in registers, the 256-node
+    tiles of a frame tile exchange row sums through memory).  Same bits as the unfused kernel + normalize pass
+    (FDNN_FUSE_NORM=0), and the same bits again when every third node tile pretends its wait timed out
+    (FDNN_GEMM_DEBUG=4096): those tiles store exp(z) unscaled and fuse_cleanup_kernel finishes them."""
+    import subprocess, sys
+
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from fast_dnn_amd import api, formats as F
+x = F.synth_features(10000, 432, seed=41)
+masks = F.generate_masks_fast(10000, 8000, 0.40, 0.03, seed=3)
+dnn = api.QuantizedDnn.loadFromFile({net_model_path!r})
+p = dnn.calculate(x)
+ctx = dnn.getNewLazyContext(10000)
+ctx.calculateUntilOutput(x)
+q = ctx.calculateForOutputNodesBatch(masks)
+ctx.delete(); dnn.delete()
+np.save(sys.argv[1], np.concatenate([p[::7], q[::7]]))
+"""
+    outs = []
+    for tag, env in (("fused", {}), ("unfused", {"FDNN_FUSE_NORM": "0"}), ("giveup", {"FDNN_GEMM_DEBUG": "4096"})):
+        f = str(tmp_path / f"{tag}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.abs(outs[0].sum(1, dtype=np.float64) - 1).max() < 1e-4
