@@ -453,7 +453,7 @@ def main() -> None:
         # WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes); bench.py
         # itself cannot run under rocprof.  Newest round first.
         pmc, pmc_file = {}, None
-        for cand in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for cand in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 pmc_file = cand
@@ -502,7 +502,10 @@ def main() -> None:
             4 * (432 * n + 432 * 2048) + 2048 * n, "l0_mfma_kernel" if args.l0_fma else ("l0_mfma_kernel", "l0_fix_kernel"))
         add("hidden_gemm", "qgemm_kernel<hidden> (int8 MFMA 32x32x32, 2048x2048 layer + dequant/bias/sigmoid-table epilogue)",
             "mfma", 2.0 * 2048 * 2048 * n, INT8_PEAK_TOPS, "TOP/s", 1e12, 2048 * 2048 + 2 * n * 2048, "qgemm_kernel hidden")
-        add("output_gemm", "qgemm_kernel<output> (int8 MFMA, 8000x2048 layer + dequant/bias/exp epilogue, 32 KB of exp(z) per frame out)",
+        fused_out = not prof["normalize"]["launches"]
+        add("output_gemm", "qgemm_kernel<output> (int8 MFMA, 8000x2048 layer + dequant/bias/exp epilogue" +
+            (" + FUSED soft-max: row sums exchanged between the 256-node tiles of a frame tile, probabilities written directly, "
+             "32 KB per frame out; includes the near-empty fuse_cleanup launch)" if fused_out else ", 32 KB of exp(z) per frame out)"),
             "mfma", 2.0 * 2048 * O * n, INT8_PEAK_TOPS, "TOP/s", 1e12, 2048 * O + n * 2048 + 4 * n * O, "qgemm_kernel output")
         add("normalize", "normalize_kernel (soft-max scale: read + write [n][8000] fp32)", "hbm", 2.0 * O * 4 * n, HBM_PEAK_GBS,
             "GB/s", 1e9, 2 * O * 4 * n, "normalize_kernel")
@@ -510,7 +513,7 @@ def main() -> None:
         gemm = next(k for k in kinds if k["kernel"].startswith("qgemm_kernel<hidden>"))
         rocprof = None
         try:  # the same fractions from the committed rocprofv3 averages (tools/profile_round.sh)
-            rocprof = json.load(open(os.path.join(ROOT, "profiles", "r02_roofline.json")))
+            rocprof = json.load(open(os.path.join(ROOT, "profiles", "r03_roofline.json")))
         except Exception:
             pass
         value = world * n * steps / elapsed
@@ -533,21 +536,22 @@ def main() -> None:
                 "frames_per_gpu": n, "global_frames": world * n, "parallelism": f"frame-sharded x{world}, replicated weights",
                 "layer0_numerics": "fused (reference built -march=native)" if args.l0_fma else "unfused (reference built -msse4, canonical)",
                 "steps_in_flight": depth,
-                "submission": "fdnn_server_submit_device: every step a complete pass into its own output buffer; the soft-max "
-                              "scale of step i runs on a second stream under layer 0 of step i+1",
+                "submission": "fdnn_server_submit_device: every step a complete pass into its own output buffer (dense steps scale "
+                              "their soft-max inside the output kernel; a lazy step's scale pass runs on a second stream under layer 0 "
+                              "of the next step)",
             },
             "x_realtime_per_gpu": round(value / world / 100.0, 1),
             "int8_tops_end_to_end": round(INT8_OPS_PER_FRAME * value / world / 1e12, 1),
             "single_stream": {"frames_per_s": round(world * n * steps / single_elapsed, 1), "ms_per_step": round(single_elapsed / steps * 1e3, 4),
                               "note": "the same K steps as back-to-back fdnn_calculate_device calls on one stream (no overlap between steps)"},
             "roofline": dict(dominant, note="largest share of the step; times from HIP events on the launch stream, which add ~4 us per "
-                                            "bracketed launch -- profiles/r02_roofline.json holds the rocprofv3 averages"),
+                                            "bracketed launch -- profiles/r03_roofline.json holds the rocprofv3 averages"),
             "roofline_int8_gemm": gemm,
             "roofline_kernels": kinds,
             "end_to_end": {"bound": "mfma", "achieved": round(value / world, 1), "peak": round(ROOFLINE_FRAMES_PER_S, 1), "unit": "frames/s per GPU",
                            "frac": round(value / world / ROOFLINE_FRAMES_PER_S, 4),
-                           "note": "5 POP/s int8 / 83.1 M int8 ops per frame; layer 0 (2 % of the MACs, fp32) and the soft-max "
-                                   "write (32 KB per frame) are not int8-MFMA work and take about a third and a ninth of the step"},
+                           "note": "5 POP/s int8 / 83.1 M int8 ops per frame; layer 0 (2 % of the MACs, fp32) is not int8-MFMA work and "
+                                   "takes about a third of the step; the 32 KB per frame of probabilities leave from inside the output kernel"},
             "traffic_source": pmc_file,
             "rocprof": rocprof,
             "setup": {"clock_ramp_steps": ramp_steps, "clock_ramp_s": args.clock_ramp_s,

@@ -989,23 +989,32 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
 // has stored exp(z) unscaled and raised its flag.  By the time this kernel runs every tile has published its row sums,
 // so the totals are complete: scale the flagged tile's block (one thread per frame), lower the flag.
 __global__ __launch_bounds__(64) void fuse_cleanup_kernel(QGemmParams p, int FT) {
-  const int MT = p.rows_pad / 256, tile = blockIdx.x, nt = tile / MT, mt = tile - nt * MT;
-  if (p.fuse_flag[tile] == 0u) return;
+  // one 64-thread workgroup per FRAME tile: normally 32 flag reads, one ballot, done (a workgroup per tile was 8192
+  // workgroups and 4 us of launch for nothing)
+  const int MT = p.rows_pad / 256, nt = blockIdx.x;
   int L = 1;
   while (L < MT) L <<= 1;
-  for (int f = threadIdx.x; f < FT; f += 64) {
-    const int frame = nt * FT + f;
-    if (frame >= p.n) continue;
-    float x[64];  // MT <= 32 on this path (qgemm_fused_ok)
-    for (int j = 0; j < 64; ++j) x[j] = j < MT ? p.fuse_s[(static_cast<size_t>(nt) * MT + j) * FT + f] : 0.0f;
-    for (int len = L >> 1; len >= 1; len >>= 1)
-      for (int i = 0; i < len; ++i) x[i] = x[2 * i] + x[2 * i + 1];
-    const float inv = 1.0f / x[0];
-    float *row = p.final + static_cast<size_t>(frame) * p.rows;
-    for (int c = mt * 256; c < min(p.rows, mt * 256 + 256); ++c) row[c] = row[c] * inv;
+  for (int mt0 = 0; mt0 < MT; mt0 += 64) {
+    const int mine = mt0 + static_cast<int>(threadIdx.x);
+    const bool flagged = mine < MT && p.fuse_flag[static_cast<size_t>(nt) * MT + mine] != 0u;
+    unsigned long long todo = __ballot(flagged);
+    while (todo) {
+      const int mt = mt0 + __ffsll(static_cast<long long>(todo)) - 1;
+      todo &= todo - 1;
+      for (int f = threadIdx.x; f < FT; f += 64) {
+        const int frame = nt * FT + f;
+        if (frame >= p.n) continue;
+        float x[64];  // MT <= 32 on this path (qgemm_fused_ok)
+        for (int j = 0; j < 64; ++j) x[j] = j < MT ? p.fuse_s[(static_cast<size_t>(nt) * MT + j) * FT + f] : 0.0f;
+        for (int len = L >> 1; len >= 1; len >>= 1)
+          for (int i = 0; i < len; ++i) x[i] = x[2 * i] + x[2 * i + 1];
+        const float inv = 1.0f / x[0];
+        float *row = p.final + static_cast<size_t>(frame) * p.rows;
+        for (int c = mt * 256; c < min(p.rows, mt * 256 + 256); ++c) row[c] = row[c] * inv;
+      }
+      if (threadIdx.x == 0) p.fuse_flag[static_cast<size_t>(nt) * MT + mt] = 0u;
+    }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) p.fuse_flag[tile] = 0u;
 }
 
 template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool FAST = true, int WM = 4>
@@ -1042,7 +1051,7 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     // fused soft-max: the node tiles of a frame tile are consecutive blocks; a second, near-empty launch scales whatever a
     // workgroup that gave up waiting left unscaled (normally nothing: every workgroup reads one flag and leaves)
     hipLaunchKernelGGL(p.mask ? k_fused_masked : k_fused, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
-    hipLaunchKernelGGL(fuse_cleanup_kernel, dim3(MT * NT), dim3(64), 0, s, p, Cfg::FT);
+    hipLaunchKernelGGL(fuse_cleanup_kernel, dim3(NT), dim3(64), 0, s, p, Cfg::FT);
   } else if (p.tap_acc)
     hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else if (OUTPUT && p.mask == nullptr && (p.rows & 31) == 0)

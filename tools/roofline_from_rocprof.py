@@ -35,7 +35,8 @@ for r in rows:
         args = nm.split("qgemm_kernel<")[1].split(">")[0].replace(" ", "").split(",")
         output = args[4] == "true"
         rows_l = O if output else H
-        ent = dict(kernel=f"qgemm_kernel<{'output' if output else 'hidden'}> {32 * int(args[0]) * int(args[1])}-frame tile", bound="mfma",
+        fused = len(args) > 11 and args[11] == "true"
+        ent = dict(kernel=f"qgemm_kernel<{'output' if output else 'hidden'}> {32 * int(args[0]) * int(args[1])}-frame tile" + (" + fused soft-max" if fused else ""), bound="mfma",
                    achieved=round(2.0 * rows_l * H * n / (avg_us * 1e-6) / 1e12, 1), peak=5000.0, unit="TOP/s",
                    algorithmic_bytes_per_launch=rows_l * H + n * H + (4 * n * O if output else n * H),
                    traffic=traffic("qgemm_kernel output" if output else "qgemm_kernel hidden"))
