@@ -31,7 +31,8 @@
 // and (r>>1)&7 for 128-byte rows (2 rows per bank row).  The XOR is applied to the
 // per-lane GLOBAL address while the LDS destination stays lane-linear, and again
 // on the ds_read_b128 fragment reads, so every 16-lane read group hits 16
-// distinct 16-byte slots (conflict free; SQ_LDS_BANK_CONFLICT ~ 0).
+// distinct 16-byte slots (the k-loop's reads are conflict free; what SQ_LDS_BANK_CONFLICT shows for this
+// kernel -- 1.2 M cycles per hidden launch -- are the epilogue's table byte gathers and tile transposition).
 #include <atomic>
 
 #include "fdnn_device.hpp"
