@@ -30,7 +30,8 @@ class FdnnError(RuntimeError):
 
 def build(verbose: bool = False) -> str:
     """Compile libfast-dnn.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    subprocess.check_call(["make", "-C", CSRC, "all"] + ([] if verbose else ["-s"]))
+    jobs = str(max(1, min(8, os.cpu_count() or 1)))  # the three kernel files take a minute each: compile them side by side
+    subprocess.check_call(["make", "-C", CSRC, "-j", jobs, "all"] + ([] if verbose else ["-s"]))
     return LIB_PATH
 
 
