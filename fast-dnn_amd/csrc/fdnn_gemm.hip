@@ -1029,7 +1029,7 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
   auto k_masked = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT, false, WM>;
   auto k_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, false, OUTPUT, WM>;
   auto k_masked_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, OUTPUT, OUTPUT, OUTPUT, WM>;
-  constexpr bool kCanFuse = OUTPUT && FAST && WM == 4 && WN == 2;
+  constexpr bool kCanFuse = OUTPUT && FAST && WM == 4 && NF >= 4;  // the 8-wave shapes and the 4-wave 128- / 160-frame shapes (two workgroups per CU)
   auto k_fused = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, false, false, WM, kCanFuse>;  // (= k_plain where it cannot)
   auto k_fused_masked = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, kCanFuse, false, WM, kCanFuse>;
   // the attribute is per device: a process may hold models on several GPUs
@@ -1206,13 +1206,16 @@ bool qgemm_fused_ok(const QGemmParams &p) {
     return e && std::atoi(e) == 0;
   }();
   if (off || p.small || !p.fastdiv || (p.mask && !p.mask_bits) || p.tap_acc || p.tap_logit || (p.rows & 31) != 0) return false;
-  if (p.frame_tile != 320 && p.frame_tile != 256) return false;
+  if (p.frame_tile != 320 && p.frame_tile != 256 && p.frame_tile != 160 && p.frame_tile != 128) return false;
   const int MT = p.rows_pad / 256;
   int L = 1;
   while (L < MT) L <<= 1;
-  // the epilogue's LDS: eight wave tiles, then 4 partial rows + the inverses + L rows of S, below the table / bias area
-  const long need = 8192 + 8 * 32 * 68 * 4 + (5L * p.frame_tile + 4 + static_cast<long>(L) * p.frame_tile) * 4;
-  const long have = static_cast<long>(256 + p.frame_tile) * 128 * 2;  // GemmCfg<.., 128, 2>::FIX_OFF
+  // the epilogue's LDS: one 32 x 64 float tile per wave, then 4 partial rows + the inverses + L rows of S, below the
+  // table / bias area (GemmCfg::FIX_OFF: two 128-byte-step stages for the 8-wave shapes, three 64-byte-step stages
+  // for the 4-wave ones)
+  const bool eight = p.frame_tile >= 256;
+  const long need = 8192 + (eight ? 8 : 4) * 32 * 68 * 4 + (5L * p.frame_tile + 4 + static_cast<long>(L) * p.frame_tile) * 4;
+  const long have = static_cast<long>(256 + p.frame_tile) * (eight ? 128 * 2 : 64 * 3);
   return L <= 32 && need <= have;
 }
 
