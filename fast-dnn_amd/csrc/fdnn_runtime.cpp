@@ -189,7 +189,7 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
   if (!lean) alloc(reinterpret_cast<void **>(&c->d_mask), np * h.out_dim);
   alloc(reinterpret_cast<void **>(&c->d_mask_bits), sizeof(uint64_t) * np * size_t((h.out_dim + 63) / 64));
   {  // fused soft-max (large dense batches): row sums per 256-node tile, counters and flags per tile (kept zero between launches)
-    const size_t mt = size_t(max_rows_pad / 256), tiles = (npt + 255) / 256 + 1;
+    const size_t mt = size_t(max_rows_pad / 256), tiles = npt / 128 + 2;  // frame tiles of 128 frames and up
     alloc(reinterpret_cast<void **>(&c->d_fuse_s), sizeof(float) * npt * mt);
     alloc(reinterpret_cast<void **>(&c->d_fuse_cnt), sizeof(uint32_t) * 2 * tiles);
     alloc(reinterpret_cast<void **>(&c->d_fuse_flag), sizeof(uint32_t) * tiles * mt);
