@@ -1025,8 +1025,8 @@ __device__ __forceinline__ float quad_bcast(float v) {
 #define FDNN_L0_FIX_THREADS 512  // 128 outputs per pass: 40.1 us against 42.6 (256), 45.4 (128), 71 (1024) for 82 000 outputs
 #endif
 constexpr int kFixThreads = FDNN_L0_FIX_THREADS;
-__global__ __launch_bounds__(kFixThreads) void l0_fix_kernel(L0Params p) {
-  constexpr int TF = 128, TN = 128;
+__global__ __launch_bounds__(kFixThreads) void l0_fix_kernel(L0Params p, int TF) {  // TF: the screening kernel's frame tile (128 or 64)
+  constexpr int TN = 128;
   typedef float v4f __attribute__((ext_vector_type(4)));
   const int node_tiles = (p.H + TN - 1) / TN;
   const int tile_id = blockIdx.x, by = tile_id / node_tiles, bx = tile_id % node_tiles;
@@ -1119,10 +1119,13 @@ void launch_mfma(const L0Params &p, hipStream_t s) {
 }
 
 // Canonical numerics through the screened path: fused chains + screening (frame norms included), exact recomputation of the flagged.
-void launch_screened(const L0Params &p, hipStream_t s) {
-  using Cfg = L0MfmaCfg<32, 4>;
-  static_assert(Cfg::TF == 128 && Cfg::TN == 128, "l0_fix_kernel assumes 128 x 128 tiles");
-  auto k_scr = l0_mfma_kernel<32, 4, false, true>;
+// WFR = 4: 128 x 128 tiles, one 512-thread workgroup per CU; WFR = 2: 64 x 128 tiles, two 256-thread workgroups per CU
+// (one's screening epilogue under the other's matrix stream, and half the batch-size staircase).
+template <int WFR>
+void launch_screened_cfg(const L0Params &p, hipStream_t s) {
+  using Cfg = L0MfmaCfg<32, WFR>;
+  static_assert(Cfg::TN == 128, "l0_fix_kernel assumes 128-node tiles");
+  auto k_scr = l0_mfma_kernel<32, WFR, false, true>;
   static std::atomic<unsigned long long> attr_set{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1131,9 +1134,22 @@ void launch_screened(const L0Params &p, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_scr), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
-  const int node_tiles = (p.H + 127) / 128, frame_tiles = (p.n_rows + 127) / 128;
+  const int node_tiles = (p.H + 127) / 128, frame_tiles = (p.n_rows + Cfg::TF - 1) / Cfg::TF;
   hipLaunchKernelGGL(k_scr, dim3(l0_grid(node_tiles, frame_tiles)), dim3(Cfg::THREADS), Cfg::LDS, s, p);
-  hipLaunchKernelGGL(l0_fix_kernel, dim3(node_tiles * frame_tiles), dim3(kFixThreads), 2 * sizeof(float) * p.D, s, p);
+  hipLaunchKernelGGL(l0_fix_kernel, dim3(node_tiles * frame_tiles), dim3(kFixThreads), 2 * sizeof(float) * p.D, s, p, Cfg::TF);
+}
+int l0_screen_wfr() {
+  static const int wfr = [] {
+    const char *e = std::getenv("FDNN_L0_SCREEN_WFR");
+    return e && std::atoi(e) == 2 ? 2 : 4;
+  }();
+  return wfr;
+}
+void launch_screened(const L0Params &p, hipStream_t s) {
+  if (l0_screen_wfr() == 2)
+    launch_screened_cfg<2>(p, s);
+  else
+    launch_screened_cfg<4>(p, s);
 }
 
 }  // namespace

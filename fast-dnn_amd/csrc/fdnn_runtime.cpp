@@ -175,7 +175,7 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
   c->xt_ld = round_up(c->cap, 128);
   alloc(reinterpret_cast<void **>(&c->d_xt), sizeof(float) * 4 * size_t(m->l0_j_pad) * c->xt_ld);
   {  // screened layer-0 path: the per-tile lists of outputs to recompute exactly
-    const size_t tiles = size_t(c->xt_ld / 128) * size_t((h.hidden + 127) / 128);
+    const size_t tiles = size_t(c->xt_ld / 64) * size_t((h.hidden + 127) / 128);  // 64- or 128-frame x 128-node screening tiles
     alloc(reinterpret_cast<void **>(&c->d_scr_count), sizeof(uint32_t) * tiles);
     alloc(reinterpret_cast<void **>(&c->d_scr_list), sizeof(uint16_t) * tiles * fdnn::kL0ScreenCap);
     if (e == hipSuccess) e = hipMemset(c->d_scr_count, 0, sizeof(uint32_t) * tiles);
