@@ -1182,15 +1182,16 @@ int qgemm_frame_tile(int rows_pad, int n) {
 
 // Batches up to this many frames take the small-batch kernel (fdnn_small.hip) where the layer allows it.  Measured
 // crossovers on the 2048-wide layers (tools/batch_sweep.py, FDNN_SMALL_MAX=0 against the default): six hidden layers
-// 60 vs 88 us at 256 frames, 80 vs 90 at 512, 104 vs 95 at 700; the 8000-node output layer 16.5 vs 24.6 at 256,
-// 25.8 vs 26.3 at 512, 47 vs 30 at 1000 (a workgroup of the small kernel walks its frame tiles one after the other).
+// (64-node tiles from ~160 frames up) 54 vs 88 us at 256 frames, 68 vs 90 at 512, 93 vs 104 at 1000, 104 vs 118 at
+// 1200, 117 vs 118 at 1500, 137 vs 121 at 2000; the 8000-node output layer 16.5 vs 24.6 at 256, 25.8 vs 26.3 at 512,
+// 44 + 15 (scale pass) vs 40 (fused) at 1000 (a workgroup of the small kernel walks its frame tiles one after the other).
 bool qgemm_small_pick(int rows_pad, int K, int n, int fastdiv, bool output) {
   static const int small_max = [] {
     const char *e = std::getenv("FDNN_SMALL_MAX");
     return e ? std::atoi(e) : -1;
   }();
   (void)rows_pad;
-  const int lim = small_max >= 0 ? small_max : output ? 512 : 640;
+  const int lim = small_max >= 0 ? small_max : output ? 512 : 1400;
   return n <= lim && qgemm_small_ok(K, fastdiv);
 }
 

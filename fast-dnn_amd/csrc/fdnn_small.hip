@@ -431,7 +431,21 @@ void launch_small_cfg(const QGemmParams &p, hipStream_t s) {
 // epilogue only; taps of the output layer need a mask-capable instance, which the tap instance is.)
 bool qgemm_small_ok(int K, int fastdiv) { return fastdiv && K <= kSmWaves * kSmSlice; }
 
-void launch_qgemm_small_hidden(const QGemmParams &p, hipStream_t s) { launch_small_cfg<1, false>(p, s); }
+// Hidden layers: 32-node tiles while a frame tile per workgroup fills the chip (up to ~128 frames on a 2048-node layer);
+// beyond, 64-node tiles halve the activation bytes per output (each workgroup then walks fewer frame tiles).
+// FDNN_SMALL_NTM=1|2 forces one shape (measurements).
+void launch_qgemm_small_hidden(const QGemmParams &p, hipStream_t s) {
+  static const int forced = [] {
+    const char *e = std::getenv("FDNN_SMALL_NTM");
+    return e ? std::atoi(e) : 0;
+  }();
+  const long wg32 = static_cast<long>(p.rows_pad / 32) * (p.n_pad / kSmFT);
+  const bool wide = forced ? forced == 2 : wg32 > 320;
+  if (wide)
+    launch_small_cfg<2, false>(p, s);
+  else
+    launch_small_cfg<1, false>(p, s);
+}
 void launch_qgemm_small_output(const QGemmParams &p, hipStream_t s) { launch_small_cfg<2, true>(p, s); }
 
 }  // namespace fdnn
