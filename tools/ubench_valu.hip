@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void valu_kernel(float *out, float x0, float w
 }
 
 template <int MODE>
-void run(const char *name, float *out) {
-  const int iters = 2000, blocks = 256 * 8;
+void run(const char *name, float *out, int per_cu = 8) {
+  const int iters = 2000, blocks = 256 * per_cu;
   float best = 1e9;
   for (int rep = 0; rep < 5; ++rep) {
     hipEvent_t e0, e1;
@@ -47,14 +47,16 @@ void run(const char *name, float *out) {
     if (ms < best) best = ms;
   }
   const double macs = double(blocks) * 256 * iters * 32;  // unfused multiply-adds
-  printf("%-8s %.3f ms  %.2f T unfused-MAC/s  (%.1f lane-MAC/clk/CU at 2.4 GHz)\n", name, best, macs / best / 1e9,
+  printf("%-8s %d waves/SIMD  %.3f ms  %.2f T unfused-MAC/s  (%.1f lane-MAC/clk/CU at 2.4 GHz)\n", name, per_cu, best, macs / best / 1e9,
          macs / (best * 1e-3) / 256 / 2.4e9);
 }
 
 int main() {
   float *out;
   hipMalloc(&out, 256 * 8 * 256 * 4);
-  run<0>("scalar", out);
-  run<1>("packed", out);
+  for (int per_cu : {1, 2, 3, 4, 8}) {  // 256-thread blocks per CU = waves per SIMD
+    run<0>("scalar", out, per_cu);
+    run<1>("packed", out, per_cu);
+  }
   return 0;
 }
