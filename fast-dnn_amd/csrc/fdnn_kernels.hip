@@ -70,7 +70,7 @@ __device__ __forceinline__ void normalize_row(const float *out, float *dst, cons
   // grid, so up to three head elements are peeled to get there and the body goes as aligned
   // dwordx4 accesses (misaligned dwordx4 accesses work but ran 0.188 ms for an 8001-wide layer,
   // the plain scalar loop 0.153, this 0.108).  Source and destination must share the offset --
-  // in place they do; the one-frame lazy call's pinned destination falls back to scalars.
+  // in place they do; the per-frame lazy call's pinned destination falls back to scalars.
   // write-through stores only when rows are whole cache lines: written through, a line shared by
   // two rows (two workgroups) becomes two partial-line writes to memory (8016-wide layer: 0.187 ms
   // against 0.118 with plain stores; 8000-wide: 0.108 against 0.112)
@@ -130,78 +130,6 @@ __global__ __launch_bounds__(256) void normalize_bg_kernel(const float *out, flo
     normalize_row<(FDNN_NORM_BG_NT != 0)>(out, dst, partial, f, partial_ld, rows, n_partial, red);
     __syncthreads();  // red[] is reused by the next row
   }
-}
-
-// ---------------------------------------------------------------- one frame of the lazy output layer
-// LazyOutputActivations (dnn.cc:355-392) for ONE frame -- the per-frame JNI call.  A 128-frame
-// GEMM tile for a single frame is 127/128 padding; here every active node is one 2048-byte
-// weight row times the frame's activation row, computed as the reference does it (u8 x s8,
-// adjacent pairs saturated to int16, dnn.cc:337-340), masked-out nodes are skipped altogether
-// (z = 0).  Workgroup t owns the 64 nodes of soft-max partial t (4 waves x 16 nodes; lane l
-// covers k = 32 l .. 32 l + 31) and reproduces the batched kernel's summation order, so a
-// frame scored here is bit-identical to the same frame scored in a batch.
-template <bool FAST>
-__global__ __launch_bounds__(256) void lazy_frame_kernel(LazyFrameParams p) {
-  __shared__ float e_s[64], half_s[2];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = blockIdx.x * 64 + wave * 16;
-  // the wave's 16 mask bytes in one load (the mask may live in host-mapped memory: one PCIe read)
-  const uint4 m16 = *reinterpret_cast<const uint4 *>(p.mask + n0);
-  const uint32_t mw[4] = {m16.x, m16.y, m16.z, m16.w};
-  // this lane's 32 activation bytes of every 64-lane row pass (K is a multiple of 128)
-  const int passes = p.K / 2048 + (p.K % 2048 ? 1 : 0);
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int node = n0 + j;  // wave-uniform
-    float e = 0.0f;
-    if (node < p.rows) {
-      float z = 0.0f;
-      if ((mw[j >> 2] >> (8 * (j & 3))) & 0xffu) {
-        int sum = 0;
-        for (int ps = 0; ps < passes; ++ps) {
-          const int k = ps * 2048 + lane * 32;
-          if (k < p.K) {
-            const uint4 a0 = *reinterpret_cast<const uint4 *>(p.a + k), a1 = *reinterpret_cast<const uint4 *>(p.a + k + 16);
-            const int8_t *wr = p.w + static_cast<size_t>(node) * p.ldw + k;
-            const uint4 w0 = *reinterpret_cast<const uint4 *>(wr), w1 = *reinterpret_cast<const uint4 *>(wr + 16);
-            const uint32_t av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const uint32_t wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-              const uint32_t au = av[d] ^ 0x80808080u;  // s8 = u8 - 128 in memory: back to u8
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                const int u0 = (au >> (16 * h)) & 0xff, u1 = (au >> (16 * h + 8)) & 0xff;
-                const int x0 = static_cast<int8_t>(wv[d] >> (16 * h)), x1 = static_cast<int8_t>(wv[d] >> (16 * h + 8));
-                sum += max(-32768, min(32767, u0 * x0 + u1 * x1));  // pmaddubsw
-              }
-            }
-          }
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);  // integers: any order
-        z = dequant<FAST>(sum, p.coef, p.rcp_coef) + p.bias[node];             // sum/coef, then += bias
-      }
-      e = __expf(z);
-    }
-    if (lane == 0) {
-      e_s[wave * 16 + j] = e;
-      if (node < p.rows) p.e_out[node] = e;
-    }
-  }
-  __syncthreads();
-  // the batched kernel's order: lane half h sums nodes 32 mi + 8 g + 4 h + q (mi, g, q ascending)
-  // starting from 0, the two halves are added last
-  if (tid < 2) {
-    float s = 0.0f;
-    for (int mi = 0; mi < 2; ++mi)
-      for (int g = 0; g < 4; ++g)
-        for (int q = 0; q < 4; ++q) s += e_s[32 * mi + 8 * g + 4 * tid + q];
-    half_s[tid] = s;
-  }
-  __syncthreads();
-  if (tid == 0) p.partial[blockIdx.x] = half_s[0] + half_s[1];
 }
 
 // ---------------------------------------------------------------- load-time check of the fast division
@@ -296,14 +224,6 @@ void launch_normalize(float *out, float *dst, const float *partial, int n, int p
     return;
   }
   hipLaunchKernelGGL(normalize_kernel, dim3(n), dim3(256), 0, s, out, dst, partial, n, partial_ld, rows, n_partial);
-}
-
-void launch_lazy_frame(const LazyFrameParams &p, hipStream_t s) {
-  const dim3 grid(p.rows_pad / 64);
-  if (p.fastdiv)
-    hipLaunchKernelGGL(lazy_frame_kernel<true>, grid, dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL(lazy_frame_kernel<false>, grid, dim3(256), 0, s, p);
 }
 
 void launch_fastdiv_check(float coef, float rcp, unsigned long long *d_mismatch, hipStream_t s) {

@@ -106,22 +106,6 @@ bool qgemm_fused_ok(const QGemmParams &p);
 void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s);
 void launch_qgemm_output(const QGemmParams &p, hipStream_t s);
 
-// One frame of the lazy output layer (the per-frame JNI call): exp(z) of every node into
-// e_out[rows], the 64-node partial sums into partial[rows_pad/64] in the batched kernel's
-// summation order; launch_normalize(e_out, dst, partial, 1, 1, ...) finishes the soft-max.
-struct LazyFrameParams {
-  const int8_t *w;      // [rows_pad][ldw]
-  const int8_t *a;      // the frame's activation row, s8 = u8 - 128, K bytes
-  const float *bias;    // [rows_pad]
-  const int8_t *mask;   // [rows_pad readable] non-zero = active (may be host-mapped)
-  float *e_out;         // [rows]
-  float *partial;       // [rows_pad / 64]
-  int rows, rows_pad, K, ldw;
-  float coef, rcp_coef;
-  int fastdiv;
-};
-void launch_lazy_frame(const LazyFrameParams &p, hipStream_t s);
-
 // bits[f][w] bit b = mask[f][64 w + b] != 0  (words per row = ceil(rows / 64); bits past the row are zero).  The lazy
 // contract's byte masks (80 MB for 10 000 frames x 8000 nodes) are read once here, at HBM speed, instead of inside the
 // output GEMM's epilogue.

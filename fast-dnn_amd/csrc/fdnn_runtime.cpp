@@ -358,32 +358,40 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   if (c->last < 0) return fail(FDNN_E_STATE, "output requested before the hidden layers were computed");
   if (first < 0 || count < 0 || first + count > c->n) return fail(FDNN_E_ARG, "frame range outside the context");
   if (count == 0) return FDNN_OK;
-  fdnn::QGemmParams g = prepare_qlayer(c, d, c->d_act[c->last] + size_t(first) * c->act_ld, count, s, true);
-  g.out = d_out;
-  g.partial = c->d_partial;
-  g.partial_ld = g.n_pad;
-  g.mask = d_masks;
-  if (d_masks && !g.small && !(taps && taps->acc_out)) {
-    // large-batch production instances: the mask travels as bits (one pass over the caller's bytes at HBM speed)
-    ProfScope ps(m, s, FDNN_PROF_OUTPUT);
-    fdnn::launch_mask_pack(d_masks, c->d_mask_bits, count, d.rows, s);
-    g.mask_bits = c->d_mask_bits;
-    g.mask_wpr = (d.rows + 63) / 64;
-  }
-  g.tap_acc = taps ? taps->acc_out : nullptr;
-  g.tap_logit = taps ? taps->logits : nullptr;
-  g.acc_probe = taps ? taps->acc_probe : nullptr;
-  g.probe_stride = taps ? std::max(1, taps->probe_stride) : 1;
-  const bool fused = !c->no_fuse && fdnn::qgemm_fused_ok(g);  // (taps exclude it; the accumulator probe of the parity tests does not)
-  if (fused) {
-    g.final = d_final ? d_final : d_out;
-    g.fuse_s = c->d_fuse_s;
-    g.fuse_cnt = c->d_fuse_cnt;
-    g.fuse_flag = c->d_fuse_flag;
-  }
+  // (One frame and decoder-sized blocks take the small-batch GEMM kernels as well: a row-by-row kernel that skips the
+  // masked-out nodes as the reference does, dnn.cc:361-365, was measured against them -- DESIGN.md section 5 -- and lost
+  // at every block size from 40 % active nodes up: the call is two launches of latency either way.)
+  bool fused = false;
+  int partial_ld = 0;
   {
-    ProfScope ps(m, s, FDNN_PROF_OUTPUT);
-    fdnn::launch_qgemm_output(g, s);
+    fdnn::QGemmParams g = prepare_qlayer(c, d, c->d_act[c->last] + size_t(first) * c->act_ld, count, s, true);
+    g.out = d_out;
+    g.partial = c->d_partial;
+    g.partial_ld = g.n_pad;
+    g.mask = d_masks;
+    if (d_masks && !g.small && !(taps && taps->acc_out)) {
+      // large-batch production instances: the mask travels as bits (one pass over the caller's bytes at HBM speed)
+      ProfScope ps(m, s, FDNN_PROF_OUTPUT);
+      fdnn::launch_mask_pack(d_masks, c->d_mask_bits, count, d.rows, s);
+      g.mask_bits = c->d_mask_bits;
+      g.mask_wpr = (d.rows + 63) / 64;
+    }
+    g.tap_acc = taps ? taps->acc_out : nullptr;
+    g.tap_logit = taps ? taps->logits : nullptr;
+    g.acc_probe = taps ? taps->acc_probe : nullptr;
+    g.probe_stride = taps ? std::max(1, taps->probe_stride) : 1;
+    fused = !c->no_fuse && fdnn::qgemm_fused_ok(g);  // (taps exclude it; the accumulator probe of the parity tests does not)
+    if (fused) {
+      g.final = d_final ? d_final : d_out;
+      g.fuse_s = c->d_fuse_s;
+      g.fuse_cnt = c->d_fuse_cnt;
+      g.fuse_flag = c->d_fuse_flag;
+    }
+    {
+      ProfScope ps(m, s, FDNN_PROF_OUTPUT);
+      fdnn::launch_qgemm_output(g, s);
+    }
+    partial_ld = g.partial_ld;
   }
   hipStream_t ns = s;
   if (tail && gemm_done) {  // the scale pass goes to the tail stream, behind the GEMM (fused: nothing is left to run
@@ -393,7 +401,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   }
   if (!fused) {
     ProfScope ps(m, ns, FDNN_PROF_NORMALIZE);
-    fdnn::launch_normalize(d_out, d_final ? d_final : d_out, c->d_partial, count, g.partial_ld, d.rows, d.rows_pad / fdnn::kPartialNodes, ns,
+    fdnn::launch_normalize(d_out, d_final ? d_final : d_out, c->d_partial, count, partial_ld, d.rows, d.rows_pad / fdnn::kPartialNodes, ns,
                            ns != s);
   }
   HIP_TRY(hipGetLastError());
@@ -772,36 +780,8 @@ int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *
   HIP_TRY(ctx_enter(c, c->stream));
   if (count <= kPinFrames) {  // the per-frame protocol: no copy commands (see fdnn_ctx)
     std::memcpy(c->h_mask_pin, masks, size_t(count) * O);
-    int rc = FDNN_OK;
-    if (count == 1) {  // one frame: a row-times-matrix kernel instead of a 128-frame GEMM tile
-      const QLayerDesc &d = h.q[h.n_q - 1];
-      const uint8_t *B = c->m->d_blob;
-      fdnn::LazyFrameParams lp{};
-      lp.w = reinterpret_cast<const int8_t *>(B + d.off_w);
-      lp.a = c->d_act[c->last] + size_t(first) * c->act_ld;
-      lp.bias = reinterpret_cast<const float *>(B + d.off_bias);
-      lp.mask = c->d_mask_pin;
-      lp.e_out = c->d_out;
-      lp.partial = c->d_partial;
-      lp.rows = d.rows;
-      lp.rows_pad = d.rows_pad;
-      lp.K = d.cols_pad - fdnn::kRowSkew;
-      lp.ldw = d.cols_pad;
-      lp.coef = d.coef;
-      lp.rcp_coef = d.rcp_coef;
-      lp.fastdiv = d.fastdiv_ok;
-      {
-        ProfScope ps(c->m, c->stream, FDNN_PROF_OUTPUT);
-        fdnn::launch_lazy_frame(lp, c->stream);
-      }
-      {
-        ProfScope ps(c->m, c->stream, FDNN_PROF_NORMALIZE);
-        fdnn::launch_normalize(c->d_out, c->d_out_pin, c->d_partial, 1, 1, d.rows, d.rows_pad / fdnn::kPartialNodes, c->stream);
-      }
-      HIP_TRY(hipGetLastError());
-    } else {
-      rc = run_output(c, first, count, c->d_mask_pin, c->d_out, c->stream, nullptr, c->d_out_pin);
-    }
+    // (run_output scores so few frames row by row, skipping the masked-out nodes)
+    const int rc = run_output(c, first, count, c->d_mask_pin, c->d_out, c->stream, nullptr, c->d_out_pin);
     ctx_leave(c, c->stream);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));

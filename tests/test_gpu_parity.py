@@ -462,11 +462,10 @@ def test_big_batch_small_net_takes_the_8_wave_shapes(tmp_models, hidden):
     dnn.delete()
 
 
-def test_one_frame_lazy_kernel_equals_the_batched_path(net_model_path, sat_model_path):
-    """The per-frame JNI call runs a row-times-matrix kernel (pmaddubsw pairs computed directly);
-    it must give bit-for-bit what the MFMA path gives for the same frame, and the oracle's
-    LazyOutputActivations numbers -- on the full 2048 -> 8000 layer and on the net whose pairs
-    really saturate."""
+def test_one_frame_lazy_call_equals_the_batched_path(net_model_path, sat_model_path):
+    """The per-frame JNI call (one 32-frame small-batch tile, 31 rows of padding) must give bit-for-bit
+    what the batch gives for the same frame, and the oracle's LazyOutputActivations numbers -- on the
+    full 2048 -> 8000 layer and on the net whose pairs really saturate."""
     x = F.synth_features(24, 432, seed=41)
     masks = F.generate_masks(24, 8000, 0.40, 0.03, seed=5)
     masks[3] = 0   # nothing active: every node comes back as 1/8000
@@ -474,7 +473,7 @@ def test_one_frame_lazy_kernel_equals_the_batched_path(net_model_path, sat_model
     dnn = api.QuantizedDnn.loadFromFile(net_model_path)
     ctx = dnn.getNewLazyContext(24)
     ctx.calculateUntilOutput(x)
-    batch = ctx.calculateForOutputNodesBatch(masks)            # 24 > 8 frames: the GEMM path
+    batch = ctx.calculateForOutputNodesBatch(masks)            # 24 > 8 frames: device staging instead of pinned
     rows = np.stack([ctx.calculateForOutputNodes(masks[i]) for i in range(24)])
     assert (rows == batch).all()
     assert np.allclose(rows[3], 1.0 / 8000, rtol=0, atol=1e-9)
@@ -494,6 +493,46 @@ def test_one_frame_lazy_kernel_equals_the_batched_path(net_model_path, sat_model
     assert np.abs(rows - g["probs"]).max() <= TIGHT            # all-active lazy == dense, saturation included
     assert (rows == dnn.calculate(xs)).all() or np.abs(rows - dnn.calculate(xs)).max() <= 1e-9
     ctx.delete()
+    dnn.delete()
+
+
+@pytest.mark.parametrize("out_dim", [1000, 1001, 1030])
+def test_small_lazy_blocks_equal_the_larger_batch(tmp_models, sat_model_path, out_dim):
+    """Decoder-sized lazy blocks (1..16 frames: the host-mapped pinned protocol up to 8, device staging above) against
+    the same frames scored inside a 40-frame block: bit for bit the same -- output widths on and off the 16-byte grid,
+    ragged frame counts, empty and full masks, any non-zero mask byte, and the net whose pairs really saturate."""
+    import os
+
+    p = os.path.join(tmp_models, f"rowwise{out_dim}.bin")
+    F.write_model_bin(p, F.synth_net([432, 128, 128, 128, out_dim], seed=300 + out_dim))
+    x = F.synth_features(40, seed=out_dim + 7)
+    masks = F.generate_masks(40, out_dim, 0.3, 0.05, seed=out_dim + 3)
+    masks[1] = 0
+    masks[2] = 1
+    masks[3] = np.where(masks[3] != 0, -7, 0)  # any non-zero byte is "active"
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    big = dnn.getNewLazyContext(40)
+    big.calculateUntilOutput(x)
+    gemm = big.calculateForOutputNodesBatch(masks)
+    big.delete()
+    assert np.abs(gemm - Oracle(p).lazy(x, masks)).max() <= TIGHT
+    for n in (1, 5, 13, 16):
+        ctx = dnn.getNewLazyContext(n)
+        ctx.calculateUntilOutput(x[:n])
+        assert np.array_equal(ctx.calculateForOutputNodesBatch(masks[:n]), gemm[:n]), n
+        ctx.delete()
+    dnn.delete()
+
+    g = golden("sat.npz")
+    dnn = api.QuantizedDnn.loadFromFile(sat_model_path)
+    xs = g["x"][:12]
+    ones = np.ones((xs.shape[0], dnn.outputDimension()), np.int8)
+    ctx = dnn.getNewLazyContext(xs.shape[0])
+    ctx.calculateUntilOutput(xs)
+    block = ctx.calculateForOutputNodesBatch(ones)
+    ctx.delete()
+    assert np.abs(block - g["probs"][:12]).max() <= TIGHT
+    assert np.array_equal(block, dnn.calculate(xs))  # all-active lazy == dense, saturation included
     dnn.delete()
 
 
