@@ -193,7 +193,7 @@ def main() -> None:
     ap.add_argument("--frames", type=int, default=0,
                     help="frames per GPU per step; default 10 000 on one GPU (BASELINE configs[2]) and 125 000 on several "
                          "(configs[4]: 1 M frames over 8 GPUs) -- the per-frame rate is the same at both sizes, large batches run "
-                         "as 10 240-frame chunks")
+                         "as chunks of two 10 240-frame workgroup rounds")
     ap.add_argument("--mode", default="gauss", choices=["gauss", "nosat"], help="synthetic weight distribution")
     ap.add_argument("--in-flight", type=int, default=2, help="steps in flight in the scoring loop (1 = no overlap between steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

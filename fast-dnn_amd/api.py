@@ -94,6 +94,7 @@ SIGNATURES = {
     "fdnn_model_blob_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
     "fdnn_model_export_blob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fdnn_model_import_blob": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
+    "fdnn_debug_frame_chunks": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int]),
     "fdnn_debug_production_acc_out": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, _c_i8p, _c_i32p, _c_f32p]),
     "fdnn_debug_forward_taps": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_i8p, _c_f32p, _c_u8p, _c_i32p, _c_i32p, _c_f32p, _c_f32p]),
     "fdnn_debug_layer0": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_u8p, C.POINTER(C.c_ulonglong)]),
@@ -566,6 +567,15 @@ def host_blob_check(blob: np.ndarray) -> dict:
     d = [C.c_int() for _ in range(4)]
     _check(lib().fdnn_host_blob_check(blob.ctypes.data_as(C.c_void_p), blob.size, *[C.byref(v) for v in d]))
     return dict(zip(("input_dim", "hidden_dim", "output_dim", "n_affine"), (int(v.value) for v in d)))
+
+
+def frame_chunks(n: int):
+    """(first frame, frame count) of every chunk a pass over ``n`` frames runs as (host logic, no device needed)."""
+    buf = (C.c_int * 4096)()
+    k = lib().fdnn_debug_frame_chunks(int(n), buf, 2048)
+    if k < 0:
+        raise ValueError("fdnn_debug_frame_chunks")
+    return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(k)]
 
 
 def host_sigmoid_lut() -> np.ndarray:

@@ -134,12 +134,18 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
 // Will run_output scale the soft-max inside the output kernel for such a call (dense, large batch)?  Then there is no
 // scale pass to hide under the next batch's layer 0.
 bool output_will_fuse(fdnn_ctx *c, int count, const int8_t *d_masks);
-// A dense pass over a very large batch runs as chunks of kChunkFrames frames (32 frame tiles of 320: one
-// workgroup per CU in the hidden layers): a chunk's 320 MB of exp(z) rows are written and re-read by its soft-max
-// scale within a working set the 256 MB Infinity Cache and the translation caches largely cover, which a
-// 125 000-frame batch (4 GB of rows) is not -- measured 10.1 M frames/s unchunked against 11.4 M chunked.  Returns
-// (offset, count) pairs; batches up to 1.5 chunks stay whole, a short tail joins the previous chunk.
-constexpr int kChunkFrames = 10240;
+// A pass over a very large batch runs as chunks (frames are independent: a chunk is a batch of its own, and the scratch
+// context only has to hold one).  kRoundFrames = 32 frame tiles of 320 = one workgroup per CU in the 2048-wide hidden
+// layers, the unit the layer times grow in; a chunk is two rounds.  Measured, 125 000 frames (the 8-GPU shard of
+// BASELINE configs[4]), fused soft-max: 12.09 M frames/s as one batch (4 GB of result rows, 512 MB of activations per
+// layer: the address-translation and Infinity caches stop covering the working set), 12.87 M in chunks of one round,
+// 13.14 M in chunks of two (tools/chunk_bench.py; round 2, unfused: 10.1 M whole, 11.4 M chunked).  Returns (offset,
+// count) pairs, the largest first.  The frames past the last whole round stay with it unless they are few
+// (<= kChunkTailSplit), in which case they are cheaper as a small batch of their own than as one more, nearly empty
+// round of workgroups in every layer.
+constexpr int kRoundFrames = 10240;
+constexpr int kChunkFrames = 2 * kRoundFrames;
+constexpr int kChunkTailSplit = 2048;
 std::vector<std::pair<int, int>> frame_chunks(int n);
 hipError_t ctx_enter(fdnn_ctx *c, hipStream_t s);
 void ctx_leave(fdnn_ctx *c, hipStream_t s);

@@ -486,16 +486,33 @@ int acquire_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
 // without the caller synchronising anything.  On one stream both calls are no-ops for the device.
 std::vector<std::pair<int, int>> frame_chunks(int n) {
   std::vector<std::pair<int, int>> out;
-  if (n <= kChunkFrames + kChunkFrames / 2) {
+  static const int kChunk = [] {  // FDNN_CHUNK_FRAMES: measurement switch (0 = never chunk; otherwise whole rounds)
+    const char *e = std::getenv("FDNN_CHUNK_FRAMES");
+    const int v = e ? std::atoi(e) : kChunkFrames;
+    return v <= 0 ? 0 : std::max(kRoundFrames, v / kRoundFrames * kRoundFrames);
+  }();
+  if (kChunk <= 0 || n <= kRoundFrames) {
     out.emplace_back(0, n);
     return out;
   }
-  int off = 0;
-  while (n - off > kChunkFrames + kChunkFrames / 4) {  // a tail of up to a quarter chunk rides with the last full one
-    out.emplace_back(off, kChunkFrames);
-    off += kChunkFrames;
+  // Whole rounds go in chunks of kChunk frames.  What is left over is less than a chunk: a SMALL tail -- a few more
+  // frame tiles than the CUs hold, i.e. one more, nearly empty round of workgroups in every layer (11 000 frames as one
+  // batch: 977 us) -- goes as a small batch of its own (754 + 150 us); from ~2 000 frames on the extra round is worth
+  // its time and the tail stays with the last whole round (14 000 frames: 1 100 us either way).  tools/batch_sweep.py,
+  // tools/chunk_bench.py.
+  const int tail = n % kRoundFrames;
+  const bool own_tail = tail > 0 && tail <= kChunkTailSplit;
+  int off = 0, body = n - tail;  // whole rounds
+  while (body - off >= kChunk) {
+    out.emplace_back(off, kChunk);
+    off += kChunk;
   }
-  out.emplace_back(off, n - off);
+  if (own_tail || tail == 0) {
+    if (body > off) out.emplace_back(off, body - off);
+    if (tail) out.emplace_back(body, tail);
+  } else {
+    out.emplace_back(off, n - off);  // the last whole rounds (if any) and the tail: less than a chunk
+  }
   return out;
 }
 
@@ -918,6 +935,17 @@ int fdnn_debug_forward_taps(fdnn_model *m, const float *x, int n, const int8_t *
   if (rc) return rc;
   if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("taps: ") + hipGetErrorString(e));
   return FDNN_OK;
+}
+
+int fdnn_debug_frame_chunks(int n, int *chunks, int cap) {
+  if (n <= 0 || !chunks || cap <= 0) return -1;
+  const auto v = fdnn::frame_chunks(n);
+  if (static_cast<int>(v.size()) > cap) return -1;
+  for (size_t i = 0; i < v.size(); ++i) {
+    chunks[2 * i] = v[i].first;
+    chunks[2 * i + 1] = v[i].second;
+  }
+  return static_cast<int>(v.size());
 }
 
 int fdnn_debug_production_acc_out(fdnn_model *m, const float *x, int n, int stride, const int8_t *masks, int32_t *acc, float *probs) {

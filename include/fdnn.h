@@ -240,6 +240,12 @@ FDNN_API int fdnn_debug_forward_taps(fdnn_model *m, const float *x, int n, const
 FDNN_API int fdnn_debug_production_acc_out(fdnn_model *m, const float *x, int n, int stride, const int8_t *masks, int32_t *acc,
                                            float *probs);
 
+/* How a pass over n frames is cut into chunks (host logic only, no device needed): chunks[2 i] = first frame,
+ * chunks[2 i + 1] = frame count of chunk i; returns the number of chunks, or -1 if `cap` pairs do not hold them.  The
+ * reference blocks a call by `batch` frames (dnn.cc:402-454: blocking never changes a result); here a very large batch
+ * runs as device-sized chunks for cache locality, results unchanged (tests / diagnostics). */
+FDNN_API int fdnn_debug_frame_chunks(int n, int *chunks, int cap);
+
 /* Which kernel computes the canonical fp32 input layer (tests / measurements only; results are
  * bit-identical): 0 = by batch size (default), 1 = always the chain-pass kernel (128 x 128
  * tiles over chain-major images), 2 = always the 64 x 64-tile kernel, 3 = the screened matrix-pipe path wherever it is

@@ -199,13 +199,13 @@ def test_host_and_device_submissions_share_one_server(mid_model_path):
 
 
 def test_very_large_batches_run_in_chunks(mid_model_path):
-    """Dense passes over more than 15 360 frames run as 10 240-frame chunks (fdnn::frame_chunks) --
+    """Dense passes over more than 20 480 frames run as chunks of whole 10 240-frame rounds (fdnn::frame_chunks) --
     back to back in fdnn_calculate_device, overlapped through the tail stream in the scoring loop,
     with and without masks.  Frames around every chunk boundary against the oracle, and the three
     paths against each other bit for bit."""
     import torch
 
-    n, O = 33000, 1000   # chunks 10240 + 10240 + 12520
+    n, O = 33000, 1000   # chunks 20480 + 12520
     x = F.synth_features(n, 432, seed=77)
     idx = np.array([0, 1, 10238, 10239, 10240, 10241, 20478, 20479, 20480, 20481, 32998, 32999])
     orc = Oracle(mid_model_path)
@@ -217,7 +217,7 @@ def test_very_large_batches_run_in_chunks(mid_model_path):
     torch.cuda.synchronize()
     assert np.abs(a[torch.from_numpy(idx).cuda()].cpu().numpy() - want).max() <= TIGHT
     assert float((a.sum(1) - 1).abs().max()) < 1e-4
-    # unchunked reference: the same frames in pieces below the chunking threshold
+    # reference: the same frames in pieces that are cut differently (10240 + 760 each)
     b = torch.zeros_like(a)
     for lo in range(0, n, 11000):
         hi = min(n, lo + 11000)
