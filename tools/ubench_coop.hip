@@ -28,6 +28,23 @@ __global__ __launch_bounds__(512) void barrier_kernel(unsigned *counter, unsigne
     cycles[1] = bad;
   }
 }
+// two-level barrier: 8 group counters (workgroup b -> group b % 8, i.e. mostly its XCD), the last arrival of a group
+// bumps the top counter, everybody polls the top counter
+__global__ __launch_bounds__(512) void barrier2_kernel(unsigned *group_cnt, unsigned *top, int rounds, long long *cycles) {
+  const unsigned nb = gridDim.x, g = blockIdx.x & 7, per = nb / 8;
+  long long t0 = __builtin_readcyclecounter();
+  for (int r = 0; r < rounds; ++r) {
+    if (threadIdx.x == 0) {
+      __atomic_thread_fence(__ATOMIC_RELEASE);
+      const unsigned prev = __hip_atomic_fetch_add(&group_cnt[g * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((prev + 1) % per == 0) __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned want = unsigned(r + 1) * 8;
+      while (__hip_atomic_load(top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && blockIdx.x == 0) cycles[0] = __builtin_readcyclecounter() - t0;
+}
 int main() {
   int *d; hipMalloc(&d, 64);
   unsigned *counter, *data; long long *cyc;
@@ -64,6 +81,19 @@ int main() {
     hipEventElapsedTime(&ms, a, b);
     long long h[2]; hipMemcpy(h, cyc, 16, hipMemcpyDeviceToHost);
     printf("grid barrier, %3d workgroups: %6.2f us per barrier (%lld cycles), stale reads %lld\n", blocks, ms * 1000 / rounds, h[0] / rounds, h[1]);
+  }
+  unsigned *gc, *top;
+  hipMalloc(&gc, 4 * 32 * 8); hipMalloc(&top, 4);
+  for (int blocks : {64, 128, 256}) {
+    const int rounds = 200;
+    hipMemsetAsync(gc, 0, 4 * 32 * 8, s);
+    hipMemsetAsync(top, 0, 4, s);
+    hipEventRecord(a, s);
+    hipLaunchKernelGGL(barrier2_kernel, dim3(blocks), dim3(512), 0, s, gc, top, rounds, cyc);
+    hipEventRecord(b, s);
+    hipStreamSynchronize(s);
+    hipEventElapsedTime(&ms, a, b);
+    printf("two-level grid barrier, %3d workgroups: %6.2f us per barrier\n", blocks, ms * 1000 / rounds);
   }
   return 0;
 }
