@@ -44,15 +44,15 @@ constexpr int kSmSlice = 256;                      // bytes of K per wave
 constexpr int kSmFT = 32;                          // frames per tile
 constexpr int kSmABuf = kSmWaves * kSmFT * kSmSlice;  // one activation tile: 64 KiB
 constexpr int kSmAuxOff = 2 * kSmABuf;             // table (3 KiB) | biases (256 B) | 128 * sum(w) (256 B) | e scratch (8 KiB)
-constexpr int kSmBiasOff = kSmAuxOff + 3072;
-constexpr int kSmWsumOff = kSmAuxOff + 3072 + 256;
+[[maybe_unused]] constexpr int kSmBiasOff = kSmAuxOff + 3072;  // (used by device code only)
+[[maybe_unused]] constexpr int kSmWsumOff = kSmAuxOff + 3072 + 256;
 constexpr int kSmEOff = kSmAuxOff + 3584;
 constexpr int kSmLds = kSmEOff + 8192 + 64;
 static_assert(kSmLds <= 160 * 1024, "LDS");
 
 // chunk c (16 bytes) of row r of a 256-byte-row LDS image lives at chunk position c ^ (r & 15): the 16 lanes of a
 // ds_read_b128 group read 16 different rows at the same k and land on 16 different 16-byte slots
-__device__ __forceinline__ int sm_pos(int row, int chunk) { return (row << 8) + (((chunk ^ row) & 15) << 4); }
+[[maybe_unused]] __device__ __forceinline__ int sm_pos(int row, int chunk) { return (row << 8) + (((chunk ^ row) & 15) << 4); }
 
 // NTM: 32-node MFMA tiles per workgroup (1: hidden layers, 2: output layer).
 template <int NTM, bool OUTPUT, bool TAP, bool MASKED>
