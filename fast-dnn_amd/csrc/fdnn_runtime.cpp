@@ -359,39 +359,34 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   if (first < 0 || count < 0 || first + count > c->n) return fail(FDNN_E_ARG, "frame range outside the context");
   if (count == 0) return FDNN_OK;
   // (One frame and decoder-sized blocks take the small-batch GEMM kernels as well: a row-by-row kernel that skips the
-  // masked-out nodes as the reference does, dnn.cc:361-365, was measured against them -- DESIGN.md section 5 -- and lost
+  // masked-out nodes as the reference does, dnn.cc:361-365, was measured against them -- DESIGN.md section 6 -- and lost
   // at every block size from 40 % active nodes up: the call is two launches of latency either way.)
-  bool fused = false;
-  int partial_ld = 0;
+  fdnn::QGemmParams g = prepare_qlayer(c, d, c->d_act[c->last] + size_t(first) * c->act_ld, count, s, true);
+  g.out = d_out;
+  g.partial = c->d_partial;
+  g.partial_ld = g.n_pad;
+  g.mask = d_masks;
+  if (d_masks && !g.small && !(taps && taps->acc_out)) {
+    // large-batch production instances: the mask travels as bits (one pass over the caller's bytes at HBM speed)
+    ProfScope ps(m, s, FDNN_PROF_OUTPUT);
+    fdnn::launch_mask_pack(d_masks, c->d_mask_bits, count, d.rows, s);
+    g.mask_bits = c->d_mask_bits;
+    g.mask_wpr = (d.rows + 63) / 64;
+  }
+  g.tap_acc = taps ? taps->acc_out : nullptr;
+  g.tap_logit = taps ? taps->logits : nullptr;
+  g.acc_probe = taps ? taps->acc_probe : nullptr;
+  g.probe_stride = taps ? std::max(1, taps->probe_stride) : 1;
+  const bool fused = !c->no_fuse && fdnn::qgemm_fused_ok(g);  // (taps exclude it; the accumulator probe of the parity tests does not)
+  if (fused) {
+    g.final = d_final ? d_final : d_out;
+    g.fuse_s = c->d_fuse_s;
+    g.fuse_cnt = c->d_fuse_cnt;
+    g.fuse_flag = c->d_fuse_flag;
+  }
   {
-    fdnn::QGemmParams g = prepare_qlayer(c, d, c->d_act[c->last] + size_t(first) * c->act_ld, count, s, true);
-    g.out = d_out;
-    g.partial = c->d_partial;
-    g.partial_ld = g.n_pad;
-    g.mask = d_masks;
-    if (d_masks && !g.small && !(taps && taps->acc_out)) {
-      // large-batch production instances: the mask travels as bits (one pass over the caller's bytes at HBM speed)
-      ProfScope ps(m, s, FDNN_PROF_OUTPUT);
-      fdnn::launch_mask_pack(d_masks, c->d_mask_bits, count, d.rows, s);
-      g.mask_bits = c->d_mask_bits;
-      g.mask_wpr = (d.rows + 63) / 64;
-    }
-    g.tap_acc = taps ? taps->acc_out : nullptr;
-    g.tap_logit = taps ? taps->logits : nullptr;
-    g.acc_probe = taps ? taps->acc_probe : nullptr;
-    g.probe_stride = taps ? std::max(1, taps->probe_stride) : 1;
-    fused = !c->no_fuse && fdnn::qgemm_fused_ok(g);  // (taps exclude it; the accumulator probe of the parity tests does not)
-    if (fused) {
-      g.final = d_final ? d_final : d_out;
-      g.fuse_s = c->d_fuse_s;
-      g.fuse_cnt = c->d_fuse_cnt;
-      g.fuse_flag = c->d_fuse_flag;
-    }
-    {
-      ProfScope ps(m, s, FDNN_PROF_OUTPUT);
-      fdnn::launch_qgemm_output(g, s);
-    }
-    partial_ld = g.partial_ld;
+    ProfScope ps(m, s, FDNN_PROF_OUTPUT);
+    fdnn::launch_qgemm_output(g, s);
   }
   hipStream_t ns = s;
   if (tail && gemm_done) {  // the scale pass goes to the tail stream, behind the GEMM (fused: nothing is left to run
@@ -401,7 +396,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   }
   if (!fused) {
     ProfScope ps(m, ns, FDNN_PROF_NORMALIZE);
-    fdnn::launch_normalize(d_out, d_final ? d_final : d_out, c->d_partial, count, partial_ld, d.rows, d.rows_pad / fdnn::kPartialNodes, ns,
+    fdnn::launch_normalize(d_out, d_final ? d_final : d_out, c->d_partial, count, g.partial_ld, d.rows, d.rows_pad / fdnn::kPartialNodes, ns,
                            ns != s);
   }
   HIP_TRY(hipGetLastError());
