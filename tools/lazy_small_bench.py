@@ -1,8 +1,7 @@
 """Decoder-sized lazy blocks, device pointers in and out: calculateForOutputNodesBatchDevice per call (the hidden
-layers are computed once, outside the timed loop).  Run once per setting of FDNN_LAZY_ROWWISE_MAX (read at first use):
-    FDNN_LAZY_ROWWISE_MAX=0  python tools/lazy_small_bench.py     # GEMM path for every block
-    FDNN_LAZY_ROWWISE_MAX=64 python tools/lazy_small_bench.py     # row by row, masked-out nodes skipped
-"""
+layers are computed once, outside the timed loop): the masked small-batch output kernel + the soft-max scale.
+(Round 3 timed a row-by-row kernel that skips the masked-out nodes against this path with this script: DESIGN.md
+section 6 has the table; the kernel is gone.)"""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
@@ -11,7 +10,6 @@ p = "/tmp/fdnn_net_seed1_gauss.bin"
 F.ensure_model_file(p, F.NET_TOPOLOGY, seed=1, mode="gauss")
 dnn = api.QuantizedDnn.loadFromFile(p)
 O = dnn.outputDimension()
-print("FDNN_LAZY_ROWWISE_MAX =", os.environ.get("FDNN_LAZY_ROWWISE_MAX", "(default)"))
 for n in (1, 2, 4, 8, 16, 32):
     x = torch.from_numpy(F.synth_features(n, 432, seed=5)).cuda()
     ctx = dnn.getNewLazyContext(n)
