@@ -196,7 +196,7 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
     if (e == hipSuccess) e = hipMemset(c->d_fuse_cnt, 0, sizeof(uint32_t) * 2 * tiles);
     if (e == hipSuccess) e = hipMemset(c->d_fuse_flag, 0, sizeof(uint32_t) * tiles * mt);
   }
-  if (e == hipSuccess && !lean)  // at least one padded row: the one-frame kernel reads the mask in 16-byte pieces up to rows_pad
+  if (e == hipSuccess && !lean)  // (at least one padded row of slack)
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mask_pin), std::max(size_t(kPinFrames) * h.out_dim, size_t(max_rows_pad)), hipHostMallocMapped);
   if (e == hipSuccess && !lean) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_mask_pin), c->h_mask_pin, 0);
   if (e == hipSuccess && !lean)
