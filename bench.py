@@ -11,6 +11,13 @@ timed region (frames are independent: weak scaling).
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` without a launcher (WORLD_SIZE unset) starts its own N ranks: it re-executes itself under
+torch.distributed.run on 127.0.0.1 with a free port and passes the exit code on.  Every N runs the SAME 10 000 frames per
+GPU per step; at N > 1 a second value is reported for 125 000 frames per GPU (BASELINE configs[4]: 1 M frames over 8 GPUs).
+`--share-device` puts every rank on device 0 (a one-GPU box: the launch, rendezvous, broadcast and timing protocol with a
+real scorer; the blob then travels over gloo, RCCL refuses two ranks on one device); `--stub-scorer` runs the same
+protocol without any GPU (gloo, host buffers, a scorer that only fills its output) -- the CPU test of the launch logic.
+
 The K timed steps are submitted to the scoring loop (fdnn_server_*, in-flight depth 2: the
 HBM-bound soft-max scale of step i runs under the VALU-bound layer 0 of step i+1, every step a
 complete pass with its own output buffer) and the clock stops when the last result is complete.
@@ -184,6 +191,116 @@ def cpu_baseline(model_path: str, frames: int = 100) -> dict:
     return out
 
 
+def self_launch(n_ranks: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: re-execute under torch.distributed.run, one rank per GPU on
+    127.0.0.1 (the container hostname may not resolve) with a free port; returns the launcher's exit code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def timed_steps(submit, drain, fence, warmup: int, steps: int) -> float:
+    """The contract's timed region: W untimed steps, then EXACTLY K steps bracketed by fence() (barrier + device sync)."""
+    for i in range(warmup):
+        submit(i)
+    drain()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        submit(i)
+    drain()
+    fence()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(dist, world: int, elapsed: float, dev) -> float:
+    if world == 1:
+        return elapsed
+    import torch
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def rank_report(dist, world: int, rank: int, digest: str, own_frames_per_s: float, device_name: str) -> dict:
+    """What the driver can check about an N-rank run: how many ranks the process group really has and on which backend,
+    that every rank holds the same weight blob (sha256 of what the rank's model exports), each rank's own rate."""
+    if world == 1:
+        return {"ranks": 1, "collective_backend": None, "rccl_ranks": 0, "blob_sha256": digest, "blob_sha256_all_equal": True,
+                "per_rank_frames_per_s": {"min": round(own_frames_per_s, 1), "max": round(own_frames_per_s, 1)}, "devices": [device_name]}
+    parts = [None] * world
+    dist.all_gather_object(parts, (rank, digest, own_frames_per_s, device_name))
+    backend = dist.get_backend()
+    rates = [p[2] for p in parts]
+    return {"ranks": dist.get_world_size(), "collective_backend": backend,
+            "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
+            "blob_sha256": parts[0][1], "blob_sha256_all_equal": len({p[1] for p in parts}) == 1,
+            "per_rank_frames_per_s": {"min": round(min(rates), 1), "max": round(max(rates), 1), "all": [round(r, 1) for r in rates]},
+            "devices": [p[3] for p in parts]}
+
+
+def stub_main(args, rank: int, world: int) -> None:
+    """--stub-scorer: the N-rank protocol of main() without a GPU.  gloo, host tensors; rank 0 quantizes and packs the tiny
+    model with the library's host half (no device needed), the blob is broadcast and validated on every rank, the timed
+    region runs a scorer that only fills its output; same fences, same max-over-ranks reduction, same multi-rank keys."""
+    import hashlib
+
+    import torch
+    import torch.distributed as dist
+
+    from fast_dnn_amd import api, dist as fd, formats as F
+
+    dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    model_path = os.path.join(tmp, "fdnn_stub_tiny.bin")
+    if rank == 0:
+        F.ensure_model_file(model_path, [432, 64, 64, 64, 100], seed=3, mode="gauss")
+    blob = torch.from_numpy(api.HostModel(model_path).blob()) if rank == 0 else None
+    blob = fd.broadcast_blob(blob, rank, world, dev)
+    info = api.host_blob_check(blob.numpy())
+    digest = hashlib.sha256(blob.numpy().tobytes()).hexdigest()
+    n = args.frames if args.frames > 0 else 256
+    O = info["output_dim"]
+    out = np.empty((n, O), dtype=np.float32)
+
+    def submit(_i):
+        out.fill(1.0 / O)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    own = timed_steps(submit, lambda: None, fence, args.warmup, args.steps)
+    elapsed = max_over_ranks(dist, world, own, dev)
+    rep = rank_report(dist, world, rank, digest, n * args.steps / own, "cpu (stub)")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "acoustic frames/sec (whole node), 7x2048->8000 nnet", "value": round(world * n * args.steps / elapsed, 1),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "none (stub scorer)", "data": "synthetic",
+            "config": {"workload": "STUB: launch / rendezvous / broadcast / timing protocol only, no scorer, no GPU", "frames_per_gpu": n,
+                       "global_frames": world * n, "parallelism": f"frame-sharded x{world}, replicated weights"},
+            "multi_gpu": rep, "stub": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,9 +308,16 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=0,
-                    help="frames per GPU per step; default 10 000 on one GPU (BASELINE configs[2]) and 125 000 on several "
-                         "(configs[4]: 1 M frames over 8 GPUs) -- the per-frame rate is the same at both sizes, large batches run "
-                         "as chunks of two 10 240-frame workgroup rounds")
+                    help="frames per GPU per step; default 10 000 at every N (BASELINE configs[2]), so that the 1 -> N ratio "
+                         "compares like with like; at N > 1 the 125 000-frame shard of configs[4] is timed as a second value "
+                         "(`config4_125k_per_gpu`, skip with --no-config4)")
+    ap.add_argument("--no-config4", action="store_true", help="N > 1: skip the 125 000-frames-per-GPU leg")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank on device 0 (one-GPU box): weights broadcast over gloo, unfused soft-max (two processes on "
+                         "one GPU must not spin on each other's workgroups, INTEGRATION.md)")
+    ap.add_argument("--stub-scorer", action="store_true",
+                    help="no GPU: gloo, host buffers and a scorer that only fills its output -- exercises launch, rendezvous, "
+                         "blob broadcast + hash, barriers, max-over-ranks timing and the JSON line (tests/test_bench_launch.py)")
     ap.add_argument("--mode", default="gauss", choices=["gauss", "nosat"], help="synthetic weight distribution")
     ap.add_argument("--in-flight", type=int, default=2, help="steps in flight in the scoring loop (1 = no overlap between steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -208,24 +332,40 @@ def main() -> None:
                     help="layer 0 with the fused multiply-add numerics of a -march=native reference build (fp32 MFMA)")
     args = ap.parse_args()
 
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))  # start the N ranks ourselves
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    if args.stub_scorer:
+        stub_main(args, rank, world)
+        return
+    if args.share_device:
+        os.environ["FDNN_FUSE_NORM"] = "0"  # before the library is loaded: several processes on one GPU take the scale pass
+
+    import hashlib
+
     import torch
     import torch.distributed as dist
 
     from fast_dnn_amd import api, formats as F
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available() or api.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: the scorer has no CPU path")
+    if args.share_device:
+        local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: no device {local} on this box ({torch.cuda.device_count()} visible); --share-device puts every rank on device 0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.share_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from fast_dnn_amd.dist import load_replicated
 
@@ -233,9 +373,16 @@ def main() -> None:
     model_path = os.path.join(tmp, f"fdnn_net_seed1_{args.mode}.bin")
     if rank == 0:
         F.ensure_model_file(model_path, F.NET_TOPOLOGY, seed=1, mode=args.mode)
-    dnn = load_replicated(model_path, local, rank, world)
+    dnn = load_replicated(model_path, local, rank, world, host_broadcast=args.share_device)
+    # what THIS rank's model holds after the broadcast, hashed on the host (compared across ranks below)
+    nb = dnn.blobSize()
+    held = torch.empty(nb, dtype=torch.uint8, device=dev)
+    dnn.exportBlob(held.data_ptr(), nb, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    blob_digest = hashlib.sha256(held.cpu().numpy().tobytes()).hexdigest()
+    del held
     O = dnn.outputDimension()
-    n = args.frames if args.frames > 0 else (FRAMES_PER_GPU if world == 1 else 125000)
+    n = args.frames if args.frames > 0 else FRAMES_PER_GPU
     depth = max(1, args.in_flight)
     if args.l0_fma:
         dnn.setInputLayerFma(True)
@@ -284,20 +431,13 @@ def main() -> None:
         return
 
     # ---- the timed region: K complete passes through the scoring loop
-    for i in range(args.warmup):
-        srv.submit_device(x.data_ptr(), n, outs[i % depth].data_ptr())
-    srv.drain()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        srv.submit_device(x.data_ptr(), n, outs[i % depth].data_ptr())
-    srv.drain()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    own_elapsed = timed_steps(lambda i: srv.submit_device(x.data_ptr(), n, outs[i % depth].data_ptr()), srv.drain, fence, args.warmup, args.steps)
+    red_dev = torch.device("cpu") if args.share_device else dev  # gloo reduces host tensors
+    elapsed = max_over_ranks(dist, world, own_elapsed, red_dev)
+    multi = rank_report(dist, world, rank, blob_digest, n * args.steps / own_elapsed,
+                        f"{torch.cuda.get_device_name(local)} #{local}")
+    multi["shared_device"] = bool(args.share_device)
+    assert multi["blob_sha256_all_equal"], "ranks hold different weight blobs"
 
     # sanity on the last outputs: soft-max rows sum to one, every in-flight buffer holds the same result
     row_sum = float(outs[0][:64].sum(1).mean().item())
@@ -315,6 +455,22 @@ def main() -> None:
         step_single()
     fence()
     single_elapsed = time.perf_counter() - t1
+
+    # ---- N > 1: BASELINE configs[4]'s shard (1 M frames over 8 GPUs = 125 000 per GPU) as a second value
+    config4 = None
+    if world > 1 and not args.no_config4 and not args.share_device:
+        n4 = 125000
+        k4 = max(5, args.steps // 10)
+        x4 = torch.from_numpy(F.synth_features(n4, 432, seed=2000 + rank)).to(dev)
+        o4 = torch.empty((n4, O), dtype=torch.float32, device=dev)
+        own4 = timed_steps(lambda i: dnn.calculate_device(x4.data_ptr(), n4, o4.data_ptr(), stream.cuda_stream), lambda: None, fence, 2, k4)
+        el4 = max_over_ranks(dist, world, own4, red_dev)
+        assert abs(float(o4[:64].sum(1).mean().item()) - 1.0) < 1e-3
+        config4 = {"workload": f"BASELINE configs[4]: {world * n4} frames per step sharded over {world} GPUs ({n4} per GPU), "
+                               "fdnn_calculate_device back to back on one stream per rank",
+                   "frames_per_s": round(world * n4 * k4 / el4, 1), "ms_per_step": round(el4 / k4 * 1e3, 4), "steps": k4,
+                   "frames_per_gpu": n4}
+        del x4, o4
 
     # ---- per-kernel HIP events over the same K steps (single stream; rank 0 reports)
     dnn.profileBegin()
@@ -343,7 +499,7 @@ def main() -> None:
         masks = F.generate_masks_fast(n, O, 0.40, 0.03, seed=11)
         active = float(masks.mean())
         md = torch.from_numpy(masks).to(dev)
-        k_lazy = max(10, args.steps // 4)
+        k_lazy = args.steps  # the same K as the dense leg
         for i in range(args.warmup):
             srv.submit_device(x.data_ptr(), n, outs[i % depth].data_ptr(), md.data_ptr())
         srv.drain()
@@ -398,6 +554,32 @@ def main() -> None:
         small["note"] = ("fdnn_calculate_device, device-resident frames in and soft-max rows out, nine launches per call (layer 0, six "
                          "hidden layers, output layer, soft-max scale) on the small-batch kernels (fdnn_small.hip, l0_small_kernel); "
                          "round 2 took 119 / 115 us for these two calls")
+
+    # ---- BASELINE configs[1]'s batch size: 1 000 frames per call, full soft-max, device resident (the reference's own
+    # 1000-frame recipe is FuncTest.java:31-38); mid-size calls are one partly filled round of workgroups per layer
+    config1 = None
+    if world == 1 and not args.no_small:
+        mid = []
+        for sn in (1000, 2000, 4000):
+            if sn > n:
+                continue
+            reps = 400
+            for _ in range(40):
+                dnn.calculate_device(x.data_ptr(), sn, outs[0].data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            t5 = time.perf_counter()
+            for _ in range(reps):
+                dnn.calculate_device(x.data_ptr(), sn, outs[0].data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t5) / reps * 1e6
+            tops = INT8_OPS_PER_FRAME * sn / (us * 1e-6) / 1e12
+            mid.append({"frames": sn, "us_per_call": round(us, 2), "ns_per_frame": round(us * 1e3 / sn, 1), "frames_per_s": round(sn / us * 1e6, 1),
+                        "int8_tops": round(tops, 1), "frac_of_int8_peak": round(tops / INT8_PEAK_TOPS, 4)})
+        assert abs(float(outs[0][:8].sum(1).mean().item()) - 1.0) < 1e-3
+        config1 = {"workload": "BASELINE configs[1] batch size: 1000 frames per fdnn_calculate_device call on the 432 -> 7x2048 -> 8000 net "
+                               "(the shipped data/16khz.bin is a FEATURE batch, SURVEY section 0; its frames tiled to 1000 are a parity test), "
+                               "calls back to back on one stream; 2000 and 4000 frames beside it",
+                   "calls": mid, **(mid[0] if mid else {})}
 
     # ---- the serving shape: 16 caller threads, 100-frame utterances (1 s of speech each), host buffers
     serving = None
@@ -522,6 +704,8 @@ def main() -> None:
             "value": round(value, 1),
             "unit": "frames/s",
             "n_gpus": world,
+            "multi_gpu": multi,
+            "config4_125k_per_gpu": config4,
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": round(step_ms, 4),
@@ -531,14 +715,13 @@ def main() -> None:
             "dtype": "int8 (u8 activations x s8 weights -> int32; fp32 layer 0 and soft-max)",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE {'configs[2]' if world == 1 else 'configs[4]'}: synthetic Kaldi nnet 432 -> 7x2048 -> 8000 "
+                "workload": f"BASELINE configs[2]{'' if world == 1 else ' on every GPU (configs[4] as config4_125k_per_gpu)'}: synthetic Kaldi nnet 432 -> 7x2048 -> 8000 "
                             f"({args.mode} weights, seed 1), {n}-frame batch per GPU, full soft-max, device-resident in/out",
                 "frames_per_gpu": n, "global_frames": world * n, "parallelism": f"frame-sharded x{world}, replicated weights",
                 "layer0_numerics": "fused (reference built -march=native)" if args.l0_fma else "unfused (reference built -msse4, canonical)",
                 "steps_in_flight": depth,
-                "submission": "fdnn_server_submit_device: every step a complete pass into its own output buffer (dense steps scale "
-                              "their soft-max inside the output kernel; a lazy step's scale pass runs on a second stream under layer 0 "
-                              "of the next step)",
+                "submission": "fdnn_server_submit_device: every step a complete pass into its own output buffer (dense and batched-lazy "
+                              "steps alike scale their soft-max inside the output kernel)",
             },
             "x_realtime_per_gpu": round(value / world / 100.0, 1),
             "int8_tops_end_to_end": round(INT8_OPS_PER_FRAME * value / world / 1e12, 1),
@@ -561,6 +744,7 @@ def main() -> None:
                 "layer0_numerics": "unfused (canonical)" if args.l0_fma else "fused (reference built -march=native), fp32 MFMA",
                 "frames_per_s_single_stream": round(alt, 1)},
             "lazy_40pct": lazy,
+            "config1_1000": config1,
             "small_batch": small,
             "serving": serving,
         }

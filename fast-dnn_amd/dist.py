@@ -46,8 +46,11 @@ def broadcast_blob(blob, rank: int, world: int, device, src: int = 0):
     return blob
 
 
-def load_replicated(model_path: str, device_index: int, rank: int, world: int):
-    """QuantizedDnn.loadFromFile on rank 0 + RCCL broadcast of the packed weights."""
+def load_replicated(model_path: str, device_index: int, rank: int, world: int, host_broadcast: bool = False):
+    """QuantizedDnn.loadFromFile on rank 0 + RCCL broadcast of the packed weights.
+
+    ``host_broadcast``: the default process group is gloo (several ranks sharing one device, where
+    RCCL refuses to start): the blob makes the trip through host memory instead."""
     import torch
 
     from . import api
@@ -63,7 +66,10 @@ def load_replicated(model_path: str, device_index: int, rank: int, world: int):
         blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         dnn.exportBlob(blob.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
-    blob = broadcast_blob(blob, rank, world, dev)
+    if host_broadcast:
+        blob = broadcast_blob(blob.cpu() if rank == 0 else None, rank, world, torch.device("cpu")).to(dev)
+    else:
+        blob = broadcast_blob(blob, rank, world, dev)
     if rank != 0:
         torch.cuda.synchronize()
         dnn = api.QuantizedDnn.fromDeviceBlob(blob.data_ptr(), blob.numel(), device_index)
