@@ -98,6 +98,7 @@ SIGNATURES = {
     "fdnn_debug_production_acc_out": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, _c_i8p, _c_i32p, _c_f32p]),
     "fdnn_debug_forward_taps": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_i8p, _c_f32p, _c_u8p, _c_i32p, _c_i32p, _c_f32p, _c_f32p]),
     "fdnn_debug_layer0": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_u8p, C.POINTER(C.c_ulonglong)]),
+    "fdnn_model_fuse_giveups": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "fdnn_profile_begin": (C.c_int, [C.c_void_p]),
     "fdnn_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "fdnn_host_model_load": (C.c_int, [C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),
@@ -446,6 +447,12 @@ class QuantizedDnn:
 
     # -- per-kernel HIP-event timing ------------------------------------------
     PROF_KINDS = ("l0", "fix", "hidden_gemm", "output_gemm", "normalize")
+
+    def fuseGiveups(self) -> int:
+        """Tiles of the fused soft-max that had to be finished by the clean-up kernel since load (fdnn_model_fuse_giveups)."""
+        v = C.c_ulonglong(0)
+        _check(lib().fdnn_model_fuse_giveups(self.nativeDnnHandle, C.byref(v)))
+        return int(v.value)
 
     def profileBegin(self) -> None:
         _check(lib().fdnn_profile_begin(self.nativeDnnHandle))

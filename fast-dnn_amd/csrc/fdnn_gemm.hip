@@ -1013,7 +1013,10 @@ __global__ __launch_bounds__(64) void fuse_cleanup_kernel(QGemmParams p, int FT)
         float *row = p.final + static_cast<size_t>(frame) * p.rows;
         for (int c = mt * 256; c < min(p.rows, mt * 256 + 256); ++c) row[c] = row[c] * inv;
       }
-      if (threadIdx.x == 0) p.fuse_flag[static_cast<size_t>(nt) * MT + mt] = 0u;
+      if (threadIdx.x == 0) {
+        p.fuse_flag[static_cast<size_t>(nt) * MT + mt] = 0u;
+        if (p.fuse_giveups) atomicAdd(p.fuse_giveups, 1ull);  // observable: fdnn_model_fuse_giveups
+      }
     }
   }
 }
@@ -1206,7 +1209,7 @@ bool qgemm_fused_ok(const QGemmParams &p) {
     const char *e = std::getenv("FDNN_FUSE_NORM");
     return e && std::atoi(e) == 0;
   }();
-  if (off || p.small || !p.fastdiv || (p.mask && !p.mask_bits) || p.tap_acc || p.tap_logit || (p.rows & 31) != 0) return false;
+  if (off || p.small || p.node_tile != 256 || !p.fastdiv || (p.mask && !p.mask_bits) || p.tap_acc || p.tap_logit || (p.rows & 31) != 0) return false;
   if (p.frame_tile != 320 && p.frame_tile != 256 && p.frame_tile != 160 && p.frame_tile != 128) return false;
   const int MT = p.rows_pad / 256;
   int L = 1;

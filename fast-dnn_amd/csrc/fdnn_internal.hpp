@@ -46,7 +46,10 @@ struct fdnn_model {
   uint8_t *d_blob = nullptr;
   float *d_w0t = nullptr;  // layer-0 weights as a chain-major image [4][l0_j_pad][l0_h_ld] (fdnn_l0.hip)
   float *d_w0norm = nullptr;  // [H] ||w_n||_2 rounded up: the node half of the screened layer-0 path's bound
-  unsigned long long *d_l0_stats = nullptr;  // [2] screened-path counters (outputs recomputed exactly at [1])
+  int8_t *d_w0d = nullptr;    // int8 screening (fdnn_l0s.hip): the layer-0 weights as three int8 digit planes, MFMA fragment order
+  float *d_w0stat = nullptr;  // [3][l0_h_ld]: 2^8 / c_n, ||w_n||_2, 2^8 b_n
+  uint16_t *d_lutpair = nullptr;  // the sigmoid table as (round-down, round-up) byte pairs
+  unsigned long long *d_l0_stats = nullptr;  // [4] device counters: [1] layer-0 outputs recomputed exactly, [2] fused soft-max tiles that gave up waiting
   int l0_jc = 0, l0_j_pad = 0, l0_h_ld = 0;
   int l0_fma = 0;
   int l0_kernel = 0;  // fdnn_debug_set_l0_kernel
@@ -54,11 +57,6 @@ struct fdnn_model {
   std::vector<fdnn_ctx *> pool;  // idle contexts owned by the model (fdnn_calculate*)
   struct fdnn_server *batcher = nullptr;  // fdnn_model_enable_batcher: fdnn_calculate goes through it
   struct fdnn_group *group = nullptr;     // fdnn_group_attach: this model leads a device group, fdnn_calculate shards over it
-  // Host-pointer calls in flight on this model (fdnn_calculate from many threads, each on its own stream).  The fused
-  // soft-max's workgroups wait for their frame tile's other node tiles; many such kernels on the chip at once can hold
-  // each other's CUs (nine partially dispatched frame tiles fill 256 CUs), which would send them all through the
-  // give-up path: beyond kMaxFusedCallers concurrent callers a call takes the unfused output kernel + scale pass.
-  std::atomic<int> host_calls{0};
   // per-kernel HIP-event timing (fdnn_profile_begin/end); off in production
   bool profiling = false;
   struct ProfRec {
@@ -83,6 +81,8 @@ struct fdnn_ctx {
   float *d_l0park = nullptr;      // [xt_ld][l0_h_ld] partial chain sums parked by the layer-0 kernel
   uint32_t *d_scr_count = nullptr;  // [frame tiles x node tiles] flagged outputs per tile (kept zero between launches)
   uint16_t *d_scr_list = nullptr;   // [tiles][kL0ScreenCap]
+  int8_t *d_xd = nullptr;           // int8 screening: the frames' digit planes [chunks][3][xt_ld / 32][1024]
+  float *d_xstat = nullptr;         // [3][xt_ld] row constants written by the pre-pass
   int8_t *d_act[2] = {nullptr, nullptr};  // [n_pad][act_ld] ping/pong, s8 = u8-128
   float *d_out = nullptr;         // [n][O]
   float *d_partial = nullptr;     // [rows_pad/64][n_pad]
@@ -93,7 +93,7 @@ struct fdnn_ctx {
   uint64_t *d_mask_bits = nullptr;  // [n][ceil(O/64)] the batched lazy call's mask as bits (launch_mask_pack)
   int last = -1;                  // d_act index holding the last hidden layer, -1 = not computed
   bool pooled = false;
-  bool no_fuse = false;           // this call must not use the fused soft-max (too many concurrent host callers)
+  bool no_fuse = false;           // this call must not use the fused soft-max
   bool l0_chain_only = false;     // scoring loop, large batches: the soft-max scale of the previous batch runs under this
                                   // batch's layer 0, which must then be the vector-pipe chain kernel (the matrix-pipe
                                   // screened path fills the register file: nothing can run beside it)
@@ -104,7 +104,6 @@ struct fdnn_ctx {
   float *h_out_pin = nullptr, *d_out_pin = nullptr;
 };
 constexpr int kPinFrames = 8;
-constexpr int kMaxFusedCallers = 4;
 
 
 namespace fdnn {

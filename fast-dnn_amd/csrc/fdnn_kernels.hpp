@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 namespace fdnn {
 
@@ -37,9 +38,23 @@ struct L0Params {
   uint32_t *scr_count; // [tiles] flagged outputs per 128 x 128 tile; zero between launches
   uint16_t *scr_list;  // [tiles][kL0ScreenCap] tile-local indices frame_row * 128 + node_col
   unsigned long long *scr_stats;  // [2] running totals: outputs screened, outputs recomputed (may be null)
+  // round 4, the screening on the INT8 matrix pipe (fdnn_l0s.hip): 24-bit integer images of both operands as three
+  // int8 digit planes in MFMA fragment order + per-row constants of the error bound.  All null = path not available.
+  int8_t *xd;          // [chunks][3][n_ld / 32][1024] frame planes, scratch, rewritten by every launch
+  float *xstat;        // [3][n_ld]: 2^16 / c_f, ||x_f||_2 (rounded up), a_f
+  const int8_t *wd;    // [chunks][3][h_ld / 32][1024] node planes (model load)
+  const float *wstat;  // [3][h_ld]: 2^8 / c_n, ||w_n||_2 (rounded up), 2^8 b_n
+  const uint16_t *lutpair;  // [1283 (+pad)] table bytes on both sides of floor(100 lin) = -641 .. 641
 };
 constexpr int kL0ScreenCap = 4096;  // listed outputs per tile (25 %); a tile that overflows is recomputed whole
 void launch_l0(const L0Params &p, hipStream_t s);
+// fdnn_l0s.hip: is the int8 screening available for this layer shape; bytes of one operand's digit planes; the node half
+// (host code, model load); pre-pass + matrix kernel (launch_l0 follows with the exact recomputation of the flagged outputs)
+bool l0_split_ok(int D, int H);
+size_t l0_split_plane_bytes(int D, int rows_ld);
+void launch_l0_split(const L0Params &p, hipStream_t s);
+void l0_split_build_weights(const float *w, const float *wnorm, const uint8_t *lut, int H, int D, int h_ld, std::vector<int8_t> *planes,
+                            std::vector<float> *stat, std::vector<uint16_t> *pairs);
 int l0_chunk_rows(int D);
 int l0_chain_node_tile();  // 64 (default: no park scratch needed) or 128 (L0Params::park must be allocated)
 void launch_l0_weight_image(const float *w, float *wt, int H, int D, int j_pad, int h_ld, hipStream_t s);
@@ -86,6 +101,7 @@ struct QGemmParams {
   float *fuse_s;
   uint32_t *fuse_cnt;
   uint32_t *fuse_flag;
+  unsigned long long *fuse_giveups;  // per model: tiles fuse_cleanup_kernel had to scale (a workgroup gave up waiting); null = not counted
   // accumulator probe of the PRODUCTION output instances (parity tests only; null otherwise): the int32 accumulators of
   // every probe_stride-th frame, [ceil(n / probe_stride)][rows] -- a wave-uniform branch in front of the epilogue
   int32_t *acc_probe;

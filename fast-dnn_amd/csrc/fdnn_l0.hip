@@ -1191,6 +1191,22 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   const bool can_screen = !p.fma && !no_screen && (p.kernel == 0 || p.kernel == 3) && !p.tap_lin && p.wnorm && p.scr_count && p.scr_list && p.n >= 2048 &&
                           p.D <= 8192;  // l0_fix_kernel stages one operand row pair in 8 D bytes of dynamic LDS (64 KB without an attribute)
   const bool can_chain = !p.fma && p.xt && p.wt && p.kernel != 2 && !(classic && p.kernel == 0);
+  // Round 4: the screening on the int8 matrix pipe (fdnn_l0s.hip: exact 24-bit integer images of both operands, eight
+  // int8 MFMA products) + the same exact recomputation of the flagged outputs.  128 x 128 tiles, 1.85 us of matrix-pipe
+  // time per tile and CU at peak: from FDNN_L0_SPLIT_MIN frames up it replaces all of the above.
+  static const bool no_split = std::getenv("FDNN_L0_NO_SPLIT") != nullptr;
+  static const int split_min = [] {
+    const char *e = std::getenv("FDNN_L0_SPLIT_MIN");
+    return e ? std::atoi(e) : 640;
+  }();
+  const bool can_split = !p.fma && !no_split && !no_screen && (p.kernel == 0 || p.kernel == 4) && !p.tap_lin && p.xd && p.xstat && p.wd && p.wstat && p.lutpair &&
+                         p.scr_count && p.scr_list && l0_split_ok(p.D, p.H);
+  if (can_split && (p.kernel == 4 || p.n >= split_min)) {
+    launch_l0_split(p, s);
+    const int node_tiles = p.h_ld / 128, frame_tiles = (p.n_rows + 127) / 128;
+    hipLaunchKernelGGL(l0_fix_kernel, dim3(node_tiles * frame_tiles), dim3(kFixThreads), 2 * sizeof(float) * p.D, s, p, 128);
+    return;
+  }
   if (can_screen && (p.kernel == 3 || (screened_us < (can_chain ? chain_us : tile64_us) && screened_us < tile64_us))) {
     launch_screened(p, s);
     return;

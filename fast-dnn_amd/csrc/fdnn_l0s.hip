@@ -1,0 +1,526 @@
+// fdnn_l0s.hip -- layer 0, canonical numerics, large batches: screening on the INT8 matrix pipe.
+//
+//   ApplyShiftAndScale + InputActivations + AddBias + QuantizedSigmoid   (dnn.cc:175-192, :219-286)
+//
+// The layer's output is the table byte of round(100 lin), lin = (l0 + l1) + (l2 + l3) + bias with l_c the reference's
+// four k-mod-4 fp32 chains (every product and every add rounded, dnn.cc:233-238, :168-172).  For all but a few
+// outputs ANY sufficiently accurate value of lin gives the same byte.  Round 2 took that value from fused chains on
+// the fp32 matrix pipe (1/16 of the bf16 rate, 235 us per 10 000 frames).  Here it comes from EXACT integer
+// arithmetic on the int8 pipe (2 x the bf16 rate):
+//
+//   frame row f:  X_k = rint(x_k c_f)  with  c_f = 8355000 / max_k |x_k|    (24-bit signed integers, |X_k| <= 8355711)
+//   node row n:   W_k = rint(w_k c_n)  likewise (model load, in double)
+//   X = 65536 X1 + 256 X2 + X3,  W likewise, balanced digits in [-128, 127]   -> three int8 planes per operand
+//   sum_k X_k W_k = 2^32 [P0 + 2^-8 P1 + 2^-16 P2 + 2^-24 P3 + 2^-32 P4],   P_o = sum over digit pairs of order o
+//   P0 = X1.W1, P1 = X1.W2 + X2.W1, P2 = X1.W3 + X2.W2 + X3.W1, P3 = X2.W3 + X3.W2: eight int8 MFMA products, int32
+//   accumulators, no rounding anywhere; P4 = X3.W3 (|P4| <= 2^14 D) is dropped and bounded.
+//
+// lin~ = sigma V + bias,  V = P0 + 2^-8 P1 + 2^-16 P2 + 2^-24 P3,  sigma = 2^32 / (c_f c_n).  What separates lin~ from the
+// reference's lin is then (a) the quantisation x c_f - X, w c_n - W, (b) P4, (c) a few float roundings of the final
+// evaluation -- all bounded per row at no cost -- and (d) the REFERENCE's own rounding errors
+//     |lin_ref - (sum_k x_k w_k + bias)|  <=  u (sum_{c,j} |s'_{c,j}| + S + 3 sum_c |l_c| + |lin_ref|),   S = sum_k |x_k w_k|,
+// s'_{c,j} its partial sums (telescoping, exact; u = 2^-24).  Partial sums are random-walk sized and S is not, so as in
+// round 2 the kernel SAMPLES them: the k order of the planes is chain-major (chain c = positions c J .. c J + J - 1,
+// J = D / 4), P0 is accumulated chain by chain (a chunk of 32 that straddles a chain boundary is issued as two MFMAs
+// with complementary byte masks on the frame operand), and after every MFMA of P0 the accumulator is added, as |.|, to
+// A.  Between two samples a, b of a chain, at most w = 32 steps apart,
+//     |s'_j| <= min(|s'_a| + F_j, |s'_b| + B_j),  F_j + B_j = (window's sum of |fl(t)| + |eps|)   =>
+//     sum_j |s'_j| <= (w/2)(|s'_a| + |s'_b|) + (w/2) S_window       (two-sided; round 2 used the one-sided form)
+// and a sample of P0 differs from the reference's partial sum by the low digits: |X W - 2^32 X1 W1| <= 2^32 0.502
+// (|X1| + |W| / 65536), i.e. per sample at most 0.502 (||X1||_1 + ||W||_1 / 65536) of the chain's rows.  Hence
+//     E = sigma (kA A + a_f + b_n) + kS ||x||_2 ||w||_2 + 10 u |bias|
+//       kA = (w + 3) u        A = sum over samples of |P0 partial|     (+3: the three combining adds and the bias add)
+//       kS = (w/2 + 2) u      (+1: the products' own roundings; +1: the x c_f multiply's rounding, u |X W|)
+//       a_f = u (w+3) m 0.502 ||X1||_1 + 2^-32 (0.5 ||X||_1 + 0.5 D + 2^14 D) + u 2^8 D     (per frame, pre-pass)
+//       b_n = u (w+3) m 0.502 ||W||_1 / 65536 + 2^-32 0.5 ||W||_1                          (per node, model load)
+//       m = samples per chain <= ceil(J / 32) + 2
+// all evaluated with upward slack; |fl(100 lin_ref) - fl(100 lin~)| <= Dd = 100.001 E + 12 u |100 lin~|.  An output is
+// flagged when a half-integer lies within Dd of 100 lin~ and the table bytes on both sides differ (ties included; NaN /
+// degenerate rows flag everything); l0_fix_kernel (fdnn_l0.hip) recomputes the flagged outputs with the exact chains.
+// Measured on the 10 000-frame bench batch: see DESIGN.md section 5.
+#include <atomic>
+#include <cmath>
+#include <limits>
+#include <type_traits>
+#include <vector>
+
+#include "fdnn_device.hpp"
+#include "fdnn_kernels.hpp"
+
+namespace fdnn {
+
+namespace {
+
+#ifndef FDNN_L0S_DEBUG
+#define FDNN_L0S_DEBUG 0  // kernel-ablation timing builds only (tools/build_variant.sh): 1 no sampling, 2 no lower-order MFMAs, 4 no screening arithmetic in the epilogue, 8 no staging in the loop
+#endif
+constexpr float kU = 5.9604645e-8f;  // 2^-24
+constexpr int kSplitW = 32;          // steps between samples at most (one MFMA = 32 k)
+constexpr int kPairEntries = 2 * kLutHalf + 3;  // table pairs for floor(100 lin) = -641 .. 641
+
+// same workgroup -> tile map as the other layer-0 kernels (fdnn_l0.hip): all node tiles of a frame tile on one XCD
+__device__ __forceinline__ bool split_tile_of_block(int node_tiles, int frame_tiles, int &bx, int &by) {
+  const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+  bx = slot % node_tiles;
+  by = xcd + 8 * (slot / node_tiles);
+  return by < frame_tiles;
+}
+
+// ---------------------------------------------------------------- pre-pass: frames -> digit planes + row constants
+// One 256-thread workgroup per 8 frames (1280 workgroups for 10 240 frames: short dependent chains, many in flight).  The
+// rows are staged (shift, scale applied: add, then multiply, dnn.cc:184-187) in LDS with an odd row stride, 32 lanes per
+// row reduce max |x|, sum x^2 and sum |x|, then every (row, 16-position half chunk) item turns its 16 values into 3 x 16
+// digit bytes.  Plane layout in memory = the MFMA fragment order, so that the matrix kernel's LDS-DMA copies are
+// lane-linear on both sides and its fragment reads are lane-linear too:
+//   xd[chunk][plane][row block of 32][half h][row r][16 bytes]  =  positions 32 chunk + 16 h + 0..15 of row 32 block + r
+constexpr int kDigFrames = 8;
+__global__ __launch_bounds__(256) void l0_digits_kernel(L0Params p, int KC, int J) {
+  extern __shared__ __attribute__((aligned(16))) float dig_smem[];
+  const int D = p.D, ld = D + 1;
+  float *xs = dig_smem;                      // [8][D + 1]
+  float *cf_s = dig_smem + kDigFrames * ld;  // [8]
+  const int tid = threadIdx.x, f0 = blockIdx.x * kDigFrames;
+  const int quads = D >> 2;
+  for (int i = tid; i < kDigFrames * quads; i += 256) {
+    const int row = i / quads, q = i - row * quads, f = f0 + row;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < p.n) {
+      const float4 raw = *reinterpret_cast<const float4 *>(p.x + static_cast<size_t>(f) * D + 4 * q);
+      const float4 sh = *reinterpret_cast<const float4 *>(p.shift + 4 * q), sc = *reinterpret_cast<const float4 *>(p.scale + 4 * q);
+      v.x = (raw.x + sh.x) * sc.x;
+      v.y = (raw.y + sh.y) * sc.y;
+      v.z = (raw.z + sh.z) * sc.z;
+      v.w = (raw.w + sh.w) * sc.w;
+    }
+    float *dst = xs + row * ld + 4 * q;
+    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+  }
+  __syncthreads();
+  {
+    const int row = tid >> 5, sub = tid & 31;
+    float mx = 0.0f, s2 = 0.0f, s1 = 0.0f;
+    int bad = 0;
+    for (int k = sub; k < D; k += 32) {
+      const float v = xs[row * ld + k], a = fabsf(v);
+      bad |= !(a < 3.0e38f);  // inf or NaN
+      mx = fmaxf(mx, a);
+      s2 = fmaf(v, v, s2);
+      s1 += a;
+    }
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      mx = fmaxf(mx, __shfl_xor(mx, off));
+      s2 += __shfl_xor(s2, off);
+      s1 += __shfl_xor(s1, off);
+      bad |= __shfl_xor(bad, off);
+    }
+    if (sub == 0) {
+      // rows the integer image cannot represent to 2^-24 of their own scale take the exact path as a whole
+      const bool degenerate = bad || mx > 1.0e18f || (mx != 0.0f && mx < 1.0e-18f);
+      const float cf = (mx == 0.0f || degenerate) ? 1.0f : 8355000.0f / mx;
+      cf_s[row] = degenerate ? 0.0f : cf;  // (digits of a degenerate row: zeros)
+      const float fD = static_cast<float>(D);
+      const float slack = 1.001f + 2.0f * kU * fD;
+      // ||X||_1 <= c_f sum|x| + D  (|X_k| <= |x_k| c_f + 1),  ||X1||_1 <= ||X||_1 / 65536 + 0.502 D
+      const float n1X = (cf * s1 * slack + fD) * 1.001f;
+      const float n1X1 = n1X * (1.0f / 65536.0f) + 0.502f * fD;
+      const float m = static_cast<float>((J + 31) / 32 + 2);
+      const float a_f = kU * (kSplitW + 3) * m * 0.502f * n1X1 + 2.3283064e-10f * (0.5f * n1X + 0.5f * fD) + kU * 256.0f * fD;
+      const int f = f0 + row;
+      if (f < p.n_ld) {
+        p.xstat[f] = 65536.0f / cf;                                       // r_f
+        p.xstat[p.n_ld + f] = sqrtf(s2) * (1.00001f + 2.0f * kU * fD);    // ||x||_2, rounded up (as the fp32 screen did)
+        p.xstat[2 * p.n_ld + f] = degenerate ? __builtin_inff() : 256.0f * a_f * 1.002f;  // (x 256: the kernel's sigma is 2^-8 sigma*)
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < kDigFrames * KC * 2; idx += 256) {
+    const int row = idx & 7, hh = (idx >> 3) & 1, kc = idx >> 4;
+    const float cf = cf_s[row];
+    uint32_t d1[4], d2[4], d3[4];
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      uint32_t w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int pp = kc * 32 + hh * 16 + e4 * 4 + e;
+        const int c = (pp >= J) + (pp >= 2 * J) + (pp >= 3 * J), j = pp - c * J;
+        const float v = pp < D ? xs[row * ld + 4 * j + c] : 0.0f;
+        const int X = static_cast<int>(rintf(v * cf));  // |X| <= 8355000 (1 + u) + 0.5
+        const int x3 = (X << 24) >> 24, r = (X - x3) >> 8, x2 = (r << 24) >> 24, x1 = (r - x2) >> 8;
+        w1 |= static_cast<uint32_t>(x1 & 0xff) << (8 * e);
+        w2 |= static_cast<uint32_t>(x2 & 0xff) << (8 * e);
+        w3 |= static_cast<uint32_t>(x3 & 0xff) << (8 * e);
+      }
+      d1[e4] = w1; d2[e4] = w2; d3[e4] = w3;
+    }
+    const int f = f0 + row;
+    if (f >= p.n_ld) continue;
+    const size_t blocks = static_cast<size_t>(p.n_ld >> 5);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const uint32_t *d = pl == 0 ? d1 : pl == 1 ? d2 : d3;
+      char *base = reinterpret_cast<char *>(p.xd) + ((static_cast<size_t>(kc) * 3 + pl) * blocks + (f >> 5)) * 1024 + hh * 512 + (f & 31) * 16;
+      *reinterpret_cast<uint4 *>(base) = make_uint4(d[0], d[1], d[2], d[3]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- the matrix kernel
+// 512 threads = 4 x 2 waves (frames x nodes), tile 128 frames x 128 nodes, wave tile 32 frames x 64 nodes = two
+// 32 x 32 MFMA tiles; per 32-position chunk a wave reads 3 frame fragments + 6 node fragments (into the register set
+// the previous chunk is not using) and issues 12 MFMAs.  Registers per lane: P0, P1, P2 and A, 32 each, + 2 x 36 of
+// fragments.  A finished chain's P0 is folded into P1 as 256 P0 (exact in int32 for D <= 496), so no fourth set.
+// Staging: per chunk 24 lane-linear 1-KiB LDS-DMA pieces (3 planes x 4 row blocks, both operands), three per wave,
+// 3-stage ring, one barrier per chunk -- placed between the chunk's two MFMA groups, so that the matrix pipe has work
+// while the waves meet, issue the next pieces and fetch the next fragments.
+constexpr int kSTF = 128, kSTN = 128, kSStage = 24 * 1024, kSStages = 3;
+constexpr int kSRing = kSStage * kSStages;
+constexpr int kSPairOff = kSRing;                    // table pairs: u16 [kPairEntries], 3 KiB
+constexpr int kSStatOff = kSRing + 3072;             // three 1-KiB slots: r_f, ||x||_2, a_f of the tile's 128 frames (512 bytes each + the DMA piece's zero tail)
+constexpr int kSLds = kSStatOff + 3 * 1024;
+constexpr int kSTS = kSTN + 16;                      // byte tile row stride
+static_assert(kSTF * kSTS + 16 + 2 * kL0ScreenCap <= kSRing, "epilogue tile and flag list must fit in the dead ring");
+
+__global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, int J) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, h = lane >> 5;
+  const int wf = wave & 3, wn = wave >> 2;
+  const int node_tiles = p.h_ld / kSTN, frame_tiles = (p.n_rows + kSTF - 1) / kSTF;
+  int bx, by;
+  if (!split_tile_of_block(node_tiles, frame_tiles, bx, by)) return;
+  const int f0 = by * kSTF, n0 = bx * kSTN;
+  const int xblocks = p.n_ld >> 5, wblocks = p.h_ld >> 5;
+
+  {  // table pairs and this tile's frame constants into the aux area (LDS-DMA, ahead of the ring)
+    const __amdgpu_buffer_rsrc_t rsrc_pair =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.lutpair), 0, (2 * kPairEntries + 15) & ~15, 0x00020000);
+    if (wave < 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_pair, FDNN_LDS_PTR(smem + kSPairOff + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
+    if (wave >= 3 && wave < 6) {  // 128 floats = 512 bytes per constant: lanes 0..31 carry them
+      const int q = wave - 3;
+      const __amdgpu_buffer_rsrc_t rsrc_st =
+          __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.xstat + static_cast<size_t>(q) * p.n_ld + f0), 0, kSTF * 4, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_st, FDNN_LDS_PTR(smem + kSStatOff + q * 1024), 16, lane * 16, 0, 0, 0);
+      // (lanes 32..63 read past num_records: zeros into the slot's own tail)
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsrc_x =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t *>(p.xd), 0, static_cast<unsigned>(KC) * 3u * static_cast<unsigned>(xblocks) * 1024u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<int8_t *>(p.wd), 0, static_cast<unsigned>(KC) * 3u * static_cast<unsigned>(wblocks) * 1024u, 0x00020000);
+  const int voff = lane * 16;
+  auto stage = [&](int kc, int buf) {
+    char *base = smem + buf * kSStage;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const int i = wave + 8 * t;  // piece: operand i / 12, plane (i % 12) / 4, row block i % 4
+      const int pl = (i % 12) >> 2, q = i & 3;
+      if (i < 12)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, FDNN_LDS_PTR(base + i * 1024), 16, voff, ((kc * 3 + pl) * xblocks + (f0 >> 5) + q) * 1024, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, FDNN_LDS_PTR(base + i * 1024), 16, voff, ((kc * 3 + pl) * wblocks + (n0 >> 5) + q) * 1024, 0, 0);
+    }
+  };
+  stage(0, 0);
+  if (KC > 1) stage(1, 1);
+  if (KC > 2) stage(2, 2);
+  asm volatile("" ::: "memory");
+
+  v16i P0[2], P1[2], P2[2];
+  float A[2][16];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      P0[s][r] = 0; P1[s][r] = 0; P2[s][r] = 0;
+      A[s][r] = 0.0f;
+    }
+  auto sample = [&](int s) {
+    if (FDNN_L0S_DEBUG & 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) A[s][r] += fabsf(static_cast<float>(P0[s][r]));
+  };
+  auto chain_end = [&](int s) {  // the finished chain's total joins P1 at its weight 2^8 (int32, exact); the next chain starts from zero
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      P1[s][r] += P0[s][r] << 8;
+      P0[s][r] = 0;
+    }
+  };
+  v4i xa[2][3], wb[2][3][2];  // fragment sets, double buffered over the chunks
+  auto load_frags = [&](int buf, int set) {  // (set is a literal at every call site: the lambdas are inlined)
+    const char *sb = smem + buf * kSStage;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      xa[set][pl] = *reinterpret_cast<const v4i *>(sb + (pl * 4 + wf) * 1024 + lane * 16);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) wb[set][pl][s] = *reinterpret_cast<const v4i *>(sb + 12288 + (pl * 4 + wn * 2 + s) * 1024 + lane * 16);
+    }
+  };
+  // P0 of one chunk for node half s, chain by chain; returns through next_b (wave-uniform)
+  auto p0_step = [&](int kc, int set, int s, int next_b) {
+    const int lo = kc * 32;
+    if (next_b == lo && next_b < p.D) {  // a chain ends exactly at the chunk edge
+      chain_end(s);
+      next_b += J;
+    }
+    const int cut = next_b - lo;
+    if (cut > 0 && cut < 32 && next_b < p.D) {
+      // the chunk straddles a chain boundary: positions below it first (complementary byte masks on the frame fragment)
+      const int keep = min(16, max(0, cut - 16 * h));  // of this lane's 16 positions
+      v4i lo_part, hi_part;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int kb = min(4, max(0, keep - 4 * d));
+        const int mask = kb == 4 ? -1 : ((1 << (8 * kb)) - 1);
+        lo_part[d] = xa[set][0][d] & mask;
+        hi_part[d] = xa[set][0][d] & ~mask;
+      }
+      P0[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo_part, wb[set][0][s], P0[s], 0, 0, 0);
+      sample(s);
+      chain_end(s);
+      P0[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi_part, wb[set][0][s], P0[s], 0, 0, 0);
+    } else {
+      P0[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][0], wb[set][0][s], P0[s], 0, 0, 0);
+    }
+  };
+  auto next_boundary = [&](int kc, int next_b) {  // the same bookkeeping as p0_step, for the scalar state
+    const int lo = kc * 32;
+    if (next_b == lo && next_b < p.D) next_b += J;
+    const int cut = next_b - lo;
+    if (cut > 0 && cut < 32 && next_b < p.D) next_b += J;
+    return next_b;
+  };
+  auto low_orders = [&](int set, int s) {
+    if (FDNN_L0S_DEBUG & 2) return;
+    P1[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][0], wb[set][1][s], P1[s], 0, 0, 0);
+    P2[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][0], wb[set][2][s], P2[s], 0, 0, 0);
+    P1[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][1], wb[set][0][s], P1[s], 0, 0, 0);
+    P2[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][1], wb[set][1][s], P2[s], 0, 0, 0);
+    P2[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][2], wb[set][0][s], P2[s], 0, 0, 0);
+  };
+
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // chunk 0 (and the aux pieces before it) landed; chunks 1, 2 may be in flight
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  load_frags(0, 0);
+  int next_b = J;  // position of the next chain boundary
+  auto chunk = [&](int kc, auto set_c) {
+    constexpr int set = decltype(set_c)::value;  // (compile time: the fragment sets are registers)
+    // ---- first MFMA group: node half 0
+    p0_step(kc, set, 0, next_b);
+    low_orders(set, 0);
+    // ---- meet: chunk kc + 1 landed for everyone, everyone has read chunk kc (its fragments are in registers)
+    if (kc + 1 < KC) {
+      if (kc + 2 < KC)
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");  // my three pieces of chunk kc + 2 may still be in flight
+      else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kc + 3 < KC && !(FDNN_L0S_DEBUG & 8)) stage(kc + 3, kc % 3);  // into the buffer chunk kc has just left
+      load_frags((kc + 1) % 3, set ^ 1);
+    }
+    // ---- second MFMA group: node half 1; the samples of half 0 ride along
+    p0_step(kc, set, 1, next_b);
+    sample(0);
+    low_orders(set, 1);
+    sample(1);
+    next_b = next_boundary(kc, next_b);
+  };
+  for (int kc = 0; kc < KC; kc += 2) {
+    chunk(kc, std::integral_constant<int, 0>{});
+    if (kc + 1 < KC) chunk(kc + 1, std::integral_constant<int, 1>{});
+  }
+  chain_end(0);  // the last chain (its final value was sampled above)
+  chain_end(1);
+
+  // ------------------------------------------------------------ epilogue
+  __syncthreads();  // the ring is dead: byte tile + flag list
+  const uint16_t *pair_s = reinterpret_cast<const uint16_t *>(smem + kSPairOff);
+  const float *rf_s = reinterpret_cast<const float *>(smem + kSStatOff);
+  const float *xn_s = rf_s + 256, *af_s = rf_s + 512;
+  uint8_t *tile = reinterpret_cast<uint8_t *>(smem);
+  uint32_t *scr_n = reinterpret_cast<uint32_t *>(tile + kSTF * kSTS);
+  uint16_t *scr_l = reinterpret_cast<uint16_t *>(tile + kSTF * kSTS + 16);
+  if (tid == 0) *scr_n = 0;
+  const float fD = static_cast<float>(p.D);
+  const float c2 = 1.001f * (0.5f * fD * fD + 2.0f * fD) * kU;  // second order in u over the D steps (as the fp32 screen)
+  const float kA = 256.0f * 1.002f * kU * (kSplitW + 3);        // (x 256: sigma below is 2^-8 sigma*)
+  const float kS = 1.002f * kU * (kSplitW / 2 + 2 + c2);
+  // this lane's node constants (two columns)
+  float bias2[2], rn2[2], kSw2[2], bn2[2], eb2[2];
+  bool node_in[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int node = n0 + wn * 64 + s * 32 + l32;
+    node_in[s] = node < p.H;
+    bias2[s] = node_in[s] ? p.bias[node] : 0.0f;
+    rn2[s] = node_in[s] ? p.wstat[node] : 0.0f;
+    kSw2[s] = kS * (node_in[s] ? p.wstat[p.h_ld + node] : 0.0f);
+    bn2[s] = node_in[s] ? p.wstat[2 * p.h_ld + node] : 0.0f;
+    eb2[s] = 10.0f * kU * fabsf(bias2[s]);
+  }
+  uint32_t scr_mask = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wf * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+    const float rf = rf_s[row], xn = xn_s[row], af = af_s[row];
+    const bool row_in = f0 + row < p.n;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      // V = 2^-8 (P1' + 2^-8 P2), P1' = 256 P0 + P1 in int32; sig = 2^24 / (c_f c_n)
+      const float v = fmaf(static_cast<float>(P2[s][r]), 0.00390625f, static_cast<float>(P1[s][r]));
+      const float sig = rf * rn2[s];
+      const float lin = fmaf(v, sig, bias2[s]);
+      const float t = lin * 100.0f;
+      const float fl = floorf(t), frac = t - fl;  // exact below 2^23
+      // the table bytes on both sides of t: entries round-down and round-up of QuantizedSigmoid::get (dnn.h:36-43)
+      const int pi = static_cast<int>(__builtin_amdgcn_fmed3f(fl, -641.0f, 641.0f)) + 641;  // (a NaN picks an end; flagged below)
+      const uint32_t pr = pair_s[pi];
+      // round(): half away from zero (dnn.h:37)
+      const bool up = (frac > 0.5f) | ((frac == 0.5f) & (t >= 0.0f));
+      const uint32_t lo_b = pr & 0xffu, hi_b = pr >> 8;
+      const uint32_t act = up ? hi_b : lo_b;
+      tile[row * kSTS + wn * 64 + s * 32 + l32] = static_cast<uint8_t>(act);
+      if (!(FDNN_L0S_DEBUG & 4)) {
+        const float E = fmaf(sig, fmaf(kA, A[s][r], af + bn2[s]), fmaf(kSw2[s], xn, eb2[s]));
+        const float Dd = fmaf(100.001f, E, fabsf(t) * (12.0f * kU)) + 1e-30f;
+        const bool near = !(fabsf(frac - 0.5f) > Dd) & !(fabsf(t) - Dd >= 641.0f);  // written so that a NaN flags
+        const bool differ = (lo_b != hi_b) | !(Dd < 0.25f);                          // several boundaries in reach: always recompute
+        // x86 float -> int turns NaN and |t| >= 2^31 into INT_MIN (entry 0 after the clamp, lut_index): anything near that takes the exact path
+        const bool huge = !(fabsf(t) < 1.0e9f);
+        const bool flag = ((near & differ) | huge) & row_in & node_in[s];
+        scr_mask |= flag ? (1u << (16 * s + r)) : 0u;
+      }
+    }
+  }
+  __syncthreads();  // (scr_n = 0 is visible; the byte tile is complete)
+  {  // the wave reserves room for all its flagged outputs with ONE LDS atomic, every lane then writes its own entries
+    const int mine = __popc(scr_mask);
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    const int wave_total = __shfl(incl, 63);
+    if (wave_total) {
+      uint32_t base = 0;
+      if (lane == 63) base = atomicAdd(scr_n, static_cast<uint32_t>(wave_total));
+      base = __shfl(base, 63);
+      uint32_t at = base + static_cast<uint32_t>(incl - mine);
+      uint32_t m = scr_mask;
+      while (m) {
+        const int i = __ffs(m) - 1;
+        m &= m - 1;
+        const int r = i & 15, sb2 = i >> 4;
+        const int row = wf * 32 + 8 * (r >> 2) + 4 * h + (r & 3), col = wn * 64 + sb2 * 32 + l32;
+        if (at < static_cast<uint32_t>(kL0ScreenCap)) scr_l[at] = static_cast<uint16_t>(row * kSTN + col);
+        ++at;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kSTF * 8 / 512; ++q) {  // the byte tile leaves as 128-byte row segments
+    const int item = tid + q * 512, row = item >> 3, c16 = (item & 7) * 16;
+    const int f = f0 + row;
+    if (f < p.n_rows && n0 + c16 < p.H)  // H is a multiple of 16
+      *reinterpret_cast<uint4 *>(p.act_out + static_cast<size_t>(f) * p.act_ld + n0 + c16) = *reinterpret_cast<const uint4 *>(tile + row * kSTS + c16);
+  }
+  __syncthreads();
+  {
+    const int tile_id = by * node_tiles + bx;
+    const uint32_t cnt = *scr_n;
+    if (tid == 0) p.scr_count[tile_id] = cnt;  // > kL0ScreenCap: the fix kernel recomputes the whole tile
+    const uint32_t listed = min(cnt, static_cast<uint32_t>(kL0ScreenCap));
+    for (uint32_t i = tid; i < listed; i += 512) p.scr_list[static_cast<size_t>(tile_id) * kL0ScreenCap + i] = scr_l[i];
+  }
+#endif
+}
+
+}  // namespace
+
+// D >= 128: a 32-position chunk meets at most one chain boundary; D <= 496: 256 P0 + P1 stays inside int32 (2^22 D + 2^15 D < 2^31)
+// and the pre-pass rows fit its LDS
+bool l0_split_ok(int D, int H) { return D >= 128 && D <= 496 && (D & 3) == 0 && (H & 15) == 0; }
+int l0_split_chunks(int D) { return (D + 31) / 32; }
+size_t l0_split_plane_bytes(int D, int rows_ld) { return static_cast<size_t>(l0_split_chunks(D)) * 3 * static_cast<size_t>(rows_ld / 32) * 1024; }
+size_t l0_split_pair_bytes() { return (2 * kPairEntries + 15) & ~size_t(15); }
+
+// Model load: the node half.  w [H][D] fp32 -> digit planes in fragment order + per-node constants {r_n, ||w||_2 (the
+// caller's), b_n}, and the table as pairs.  Host code, double arithmetic: w c_n is exact in double, so |w c_n - W| <= 0.5.
+void l0_split_build_weights(const float *w, const float *wnorm, const uint8_t *lut, int H, int D, int h_ld, std::vector<int8_t> *planes,
+                            std::vector<float> *stat, std::vector<uint16_t> *pairs) {
+  const int J = D / 4;
+  planes->assign(l0_split_plane_bytes(D, h_ld), 0);
+  stat->assign(static_cast<size_t>(3) * h_ld, 0.0f);
+  pairs->assign(l0_split_pair_bytes() / 2, 0);
+  for (int i = 0; i < kPairEntries; ++i) {  // entry i: floor(100 lin) = i - 641; bytes lut[clamp(.)] and lut[clamp(. + 1)]
+    const int lo = std::max(-kLutHalf, std::min(kLutHalf, i - 641)), hi = std::max(-kLutHalf, std::min(kLutHalf, i - 640));
+    (*pairs)[i] = static_cast<uint16_t>(lut[lo + kLutHalf] | (lut[hi + kLutHalf] << 8));
+  }
+  const size_t blocks = static_cast<size_t>(h_ld / 32);
+  const double u = std::ldexp(1.0, -24);
+  const double m = static_cast<double>((J + 31) / 32 + 2);
+  for (int n = 0; n < H; ++n) {
+    const float *row = w + static_cast<size_t>(n) * D;
+    double mx = 0.0;
+    bool bad = false;
+    for (int k = 0; k < D; ++k) {
+      const double a = std::fabs(static_cast<double>(row[k]));
+      if (!(a < 3.0e38)) bad = true;
+      if (a > mx) mx = a;
+    }
+    const bool degenerate = bad || mx > 1.0e18 || (mx != 0.0 && mx < 1.0e-18);
+    const float cn = (mx == 0.0 || degenerate) ? 1.0f : static_cast<float>(8355000.0 / mx);
+    double n1W = 0.0, n1W2 = 0.0, n1W3 = 0.0;
+    for (int pp = 0; pp < D; ++pp) {
+      const int c = pp / J, j = pp - c * J, k = 4 * j + c;
+      const long W = degenerate ? 0 : std::lrint(static_cast<double>(row[k]) * static_cast<double>(cn));
+      n1W += static_cast<double>(W < 0 ? -W : W);
+      const int x3 = static_cast<int8_t>(W & 0xff), r = static_cast<int>((W - x3) >> 8), x2 = static_cast<int8_t>(r & 0xff), x1 = (r - x2) >> 8;
+      n1W2 += std::abs(x2);
+      n1W3 += std::abs(x3);
+      const int digit[3] = {x1, x2, x3};
+      const int kc = pp >> 5, hh = (pp >> 4) & 1, e = pp & 15;
+      for (int pl = 0; pl < 3; ++pl)
+        (*planes)[((static_cast<size_t>(kc) * 3 + pl) * blocks + (n >> 5)) * 1024 + hh * 512 + (n & 31) * 16 + e] = static_cast<int8_t>(digit[pl]);
+    }
+    // sampling resolution + quantisation + the dropped orders: |P3| <= 128 (||W2||_1 + ||W3||_1) (|X2|, |X3| <= 128), |P4| <= 128 ||W3||_1
+    const double b_n = (u * (kSplitW + 3) * m * 0.502 * n1W / 65536.0 + std::ldexp(0.5 * n1W, -32) + std::ldexp(128.0 * (n1W2 + n1W3), -24) +
+                        std::ldexp(128.0 * n1W3, -32)) * 1.002;
+    auto up = [](double v) {
+      float f = static_cast<float>(v);
+      if (static_cast<double>(f) < v) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+      return f;
+    };
+    (*stat)[n] = 256.0f / cn;  // sigma = r_f r_n = 2^24 / (c_f c_n) = 2^-8 sigma*
+    (*stat)[static_cast<size_t>(h_ld) + n] = wnorm[n];
+    (*stat)[static_cast<size_t>(2) * h_ld + n] = degenerate ? std::numeric_limits<float>::infinity() : up(256.0 * b_n);
+  }
+}
+
+// pre-pass + matrix kernel; the caller (fdnn_l0.hip: launch_l0) follows with l0_fix_kernel on the same tile lists
+void launch_l0_split(const L0Params &p, hipStream_t s) {
+  const int KC = l0_split_chunks(p.D), J = p.D / 4;
+  static std::atomic<unsigned long long> attr_set{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long dev_bit = 1ull << (dev & 63);
+  const int dig_lds = (kDigFrames * (p.D + 1) + kDigFrames) * 4;
+  if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {
+    hipFuncSetAttribute(reinterpret_cast<const void *>(l0_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSLds);
+    attr_set.fetch_or(dev_bit, std::memory_order_release);
+  }
+  const int frame_tiles = (p.n_rows + kSTF - 1) / kSTF, node_tiles = p.h_ld / kSTN;
+  const int dig_rows = frame_tiles * kSTF;  // every row a matrix tile will read (<= n_ld)
+  hipLaunchKernelGGL(l0_digits_kernel, dim3(dig_rows / kDigFrames), dim3(256), dig_lds, s, p, KC, J);
+  hipLaunchKernelGGL(l0_split_kernel, dim3(static_cast<unsigned>(node_tiles) * ((frame_tiles + 7) / 8) * 8), dim3(512), kSLds, s, p, KC, J);
+}
+
+}  // namespace fdnn

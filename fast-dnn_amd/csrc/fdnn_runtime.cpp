@@ -118,8 +118,20 @@ int build_l0_image(fdnn_model *m) {
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_w0norm), sizeof(float) * wn.size()));
     HIP_TRY(hipMemcpy(m->d_w0norm, wn.data(), sizeof(float) * wn.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_l0_stats), 2 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(m->d_l0_stats, 0, 2 * sizeof(unsigned long long)));
+    if (fdnn::l0_split_ok(h.in_dim, h.hidden)) {  // the node half of the int8 screening (fdnn_l0s.hip): digit planes + constants
+      std::vector<int8_t> planes;
+      std::vector<float> stat;
+      std::vector<uint16_t> pairs;
+      fdnn::l0_split_build_weights(w0, wn.data(), m->hm.blob.data() + h.off_lut, h.hidden, h.in_dim, m->l0_h_ld, &planes, &stat, &pairs);
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_lutpair), sizeof(uint16_t) * pairs.size()));
+      HIP_TRY(hipMemcpy(m->d_lutpair, pairs.data(), sizeof(uint16_t) * pairs.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_w0d), planes.size()));
+      HIP_TRY(hipMemcpy(m->d_w0d, planes.data(), planes.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_w0stat), sizeof(float) * stat.size()));
+      HIP_TRY(hipMemcpy(m->d_w0stat, stat.data(), sizeof(float) * stat.size(), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_l0_stats), 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(m->d_l0_stats, 0, 4 * sizeof(unsigned long long)));
   }
   HIP_TRY(hipDeviceSynchronize());
   return FDNN_OK;
@@ -133,6 +145,8 @@ void destroy_ctx(fdnn_ctx *c) {
   hipFree(c->d_xt);
   hipFree(c->d_l0park);
   hipFree(c->d_scr_count);
+  hipFree(c->d_xd);
+  hipFree(c->d_xstat);
   hipFree(c->d_scr_list);
   hipFree(c->d_act[0]);
   hipFree(c->d_act[1]);
@@ -179,6 +193,10 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
     alloc(reinterpret_cast<void **>(&c->d_scr_count), sizeof(uint32_t) * tiles);
     alloc(reinterpret_cast<void **>(&c->d_scr_list), sizeof(uint16_t) * tiles * fdnn::kL0ScreenCap);
     if (e == hipSuccess) e = hipMemset(c->d_scr_count, 0, sizeof(uint32_t) * tiles);
+  }
+  if (m->d_w0d) {  // int8 screening: the frames' digit planes and row constants
+    alloc(reinterpret_cast<void **>(&c->d_xd), fdnn::l0_split_plane_bytes(h.in_dim, c->xt_ld));
+    alloc(reinterpret_cast<void **>(&c->d_xstat), sizeof(float) * 3 * size_t(c->xt_ld));
   }
   if (fdnn::l0_chain_node_tile() == 128)  // the 64-node tile keeps its partial sums in registers
     alloc(reinterpret_cast<void **>(&c->d_l0park), sizeof(float) * size_t(c->xt_ld) * m->l0_h_ld);
@@ -311,6 +329,11 @@ void run_layer0(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) 
   l0.scr_count = c->d_scr_count;
   l0.scr_list = c->d_scr_list;
   l0.scr_stats = m->d_l0_stats;
+  l0.xd = c->d_xd;
+  l0.xstat = c->d_xstat;
+  l0.wd = m->d_w0d;
+  l0.wstat = m->d_w0stat;
+  l0.lutpair = m->d_lutpair;
   l0.j_pad = m->l0_j_pad;
   l0.jc = m->l0_jc;
   l0.n_ld = c->xt_ld;
@@ -350,6 +373,17 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
 // over frames [first, first+count) of the context's last hidden activations.
 // Rows [first+count, first+n_pad) are read by the GEMM as padding frames; the
 // activation buffers carry one tile of slack rows for that.
+// One chain of fused soft-max launches per device (see run_output).
+struct FuseChain {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;  // recorded after the device's latest fused output launch
+  bool recorded = false;
+};
+static FuseChain &fuse_chain(int device) {
+  static FuseChain chains[64];
+  return chains[device & 63];
+}
+
 int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out, hipStream_t s, const Taps *taps,
                float *d_final, hipStream_t tail, hipEvent_t gemm_done) {  // d_final: where the probabilities go (default: in place in d_out)
   fdnn_model *m = c->m;
@@ -383,10 +417,27 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
     g.fuse_s = c->d_fuse_s;
     g.fuse_cnt = c->d_fuse_cnt;
     g.fuse_flag = c->d_fuse_flag;
+    g.fuse_giveups = m->d_l0_stats ? m->d_l0_stats + 2 : nullptr;
   }
   {
     ProfScope ps(m, s, FDNN_PROF_OUTPUT);
-    fdnn::launch_qgemm_output(g, s);
+    if (fused) {
+      // The fused kernel's workgroups wait for their frame tile's other node tiles, which is safe while ONE such kernel is
+      // being dispatched (in block order: the oldest unfinished frame tile always has all its workgroups resident) and a
+      // latency cliff when several are -- nine partially dispatched frame tiles fill the 256 CUs and every one of them sits
+      // in its bounded wait.  So the fused launches of a DEVICE form one chain, whatever stream, context, model or entry
+      // point they come from: each waits for the previous one's event and records its own.  Other kernels overlap them
+      // freely (they wait for nothing).  Two PROCESSES on one GPU cannot be chained: FDNN_FUSE_NORM=0.
+      FuseChain &fc = fuse_chain(m->device);
+      std::lock_guard<std::mutex> lk(fc.mu);
+      if (!fc.ev) HIP_TRY(hipEventCreateWithFlags(&fc.ev, hipEventDisableTiming));
+      if (fc.recorded) HIP_TRY(hipStreamWaitEvent(s, fc.ev, 0));  // (a wait on the stream's own last record is free)
+      fdnn::launch_qgemm_output(g, s);
+      HIP_TRY(hipEventRecord(fc.ev, s));
+      fc.recorded = true;
+    } else {
+      fdnn::launch_qgemm_output(g, s);
+    }
   }
   hipStream_t ns = s;
   if (tail && gemm_done) {  // the scale pass goes to the tail stream, behind the GEMM (fused: nothing is left to run
@@ -564,13 +615,10 @@ int calculate_on_one_device(fdnn_model *m, const float *x, int n, int dim, int b
   hipError_t e = hipStreamWaitEvent(s, c->done, 0);
   if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x, sizeof(float) * size_t(n) * dim, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
-    c->no_fuse = m->host_calls.fetch_add(1, std::memory_order_relaxed) >= kMaxFusedCallers;  // (see fdnn_model::host_calls)
     rc = run_hidden(c, c->d_x, s, nullptr);
     if (!rc) rc = run_output(c, 0, n, nullptr, c->d_out, s, nullptr);
     if (!rc) rc = copy_out(out, c->d_out, sizeof(float) * size_t(n) * h.out_dim, s);
     if (rc) hipStreamSynchronize(s);
-    m->host_calls.fetch_sub(1, std::memory_order_relaxed);  // the stream is idle again here
-    c->no_fuse = false;
   }
   release_ctx(c, s);
   if (rc) return rc;
@@ -610,6 +658,9 @@ int fdnn_model_load_on(const char *path, float cutoff, int device, fdnn_model **
     if (m->d_blob) hipFree(m->d_blob);
     if (m->d_w0t) hipFree(m->d_w0t);
     if (m->d_w0norm) hipFree(m->d_w0norm);
+    if (m->d_w0d) hipFree(m->d_w0d);
+    if (m->d_w0stat) hipFree(m->d_w0stat);
+    if (m->d_lutpair) hipFree(m->d_lutpair);
     if (m->d_l0_stats) hipFree(m->d_l0_stats);
     delete m;
     return rc;
@@ -690,6 +741,9 @@ void fdnn_model_free(fdnn_model *m) {
     hipFree(m->d_blob);
     hipFree(m->d_w0t);
     hipFree(m->d_w0norm);
+    hipFree(m->d_w0d);
+    hipFree(m->d_w0stat);
+    hipFree(m->d_lutpair);
     hipFree(m->d_l0_stats);
   }
   delete m;
@@ -718,7 +772,7 @@ int fdnn_model_set_l0_fma(fdnn_model *m, int on) {
 
 int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind) {
   if (!m) return fail(FDNN_E_ARG, "null model");
-  if (kind < 0 || kind > 3) return fail(FDNN_E_ARG, "layer-0 kernel kind must be 0, 1, 2 or 3");
+  if (kind < 0 || kind > 4) return fail(FDNN_E_ARG, "layer-0 kernel kind must be 0 .. 4");
   m->l0_kernel = kind;
   return FDNN_OK;
 }
@@ -792,7 +846,9 @@ int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *
   HIP_TRY(ctx_enter(c, c->stream));
   if (count <= kPinFrames) {  // the per-frame protocol: no copy commands (see fdnn_ctx)
     std::memcpy(c->h_mask_pin, masks, size_t(count) * O);
-    // (run_output scores so few frames row by row, skipping the masked-out nodes)
+    // (blocks of 1..8 frames go through the small GEMM kernel's 32-frame tile, which reads the mask bytes straight from the
+    // host-mapped staging; nets the small kernel cannot take -- K > 2048, no validated fast division -- fall to the large
+    // tiles behind a mask_pack pass over the same staging)
     const int rc = run_output(c, first, count, c->d_mask_pin, c->d_out, c->stream, nullptr, c->d_out_pin);
     ctx_leave(c, c->stream);
     if (rc) return rc;
@@ -972,6 +1028,16 @@ int fdnn_debug_production_acc_out(fdnn_model *m, const float *x, int n, int stri
   return FDNN_OK;
 }
 
+int fdnn_model_fuse_giveups(fdnn_model *m, unsigned long long *tiles) {
+  if (!m || !tiles) return fail(FDNN_E_ARG, "null argument");
+  *tiles = 0;
+  if (!m->d_l0_stats) return FDNN_OK;
+  DeviceGuard g(m->device);
+  const hipError_t e = hipMemcpy(tiles, m->d_l0_stats + 2, sizeof(*tiles), hipMemcpyDeviceToHost);  // (synchronizes with the device)
+  if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("fuse_giveups: ") + hipGetErrorString(e));
+  return FDNN_OK;
+}
+
 int fdnn_debug_layer0(fdnn_model *m, const float *x, int n, uint8_t *u8_out, unsigned long long *recomputed) {
   if (!m || !x || !u8_out || n <= 0) return fail(FDNN_E_ARG, "bad argument");
   DeviceGuard g(m->device);
@@ -1087,6 +1153,9 @@ int fdnn_model_import_blob(const void *d_src, size_t bytes, int device, fdnn_mod
     hipFree(m->d_blob);
     if (m->d_w0t) hipFree(m->d_w0t);
     if (m->d_w0norm) hipFree(m->d_w0norm);
+    if (m->d_w0d) hipFree(m->d_w0d);
+    if (m->d_w0stat) hipFree(m->d_w0stat);
+    if (m->d_lutpair) hipFree(m->d_lutpair);
     if (m->d_l0_stats) hipFree(m->d_l0_stats);
     delete m;
     return rc;

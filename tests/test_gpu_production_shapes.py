@@ -360,3 +360,58 @@ np.save(sys.argv[1], np.concatenate([p[::7], q[::7]]))
         outs.append(np.load(f))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert np.abs(outs[0].sum(1, dtype=np.float64) - 1).max() < 1e-4
+
+
+@pytest.mark.parametrize("kind", [4, 3])
+def test_both_screening_kernels_are_bit_exact(net_model_path, kind):
+    """Round 4 moved the screening of large-batch layer 0 from the fp32 matrix pipe (kind 3) to exact integer arithmetic
+    on the int8 pipe (kind 4, fdnn_l0s.hip): 24-bit integer images of both operands, eight int8 MFMA products, sampled
+    partial sums, a rigorous bound, exact recomputation of the flagged outputs (dnn.cc:219-247).  Both stay selectable;
+    each against the oracle over 3000 x 2048 bytes at a ragged frame count."""
+    n = 3000 + 37
+    x = F.synth_features(n, 432, seed=12)
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    dnn.setInputLayerKernel(kind)
+    got, recomputed = dnn.layer0(x)
+    if not os.environ.get("FDNN_L0_NO_SCREEN"):
+        assert 0 < recomputed < 0.05 * n * 2048, recomputed
+    orc = Oracle(net_model_path)
+    for lo in range(0, n, 512):
+        _, t = orc.calculate(x[lo:lo + 512], taps=True)
+        bad = np.argwhere(got[lo:lo + 512] != t["u8_acts"][0])
+        assert bad.size == 0, (kind, lo, bad[:5].tolist())
+    dnn.delete()
+
+
+def test_int8_screening_with_hostile_rows(net_model_path):
+    """What the 24-bit integer image of a frame row cannot represent must fall to the exact path, never to a wrong byte:
+    rows with one element 10^6 times the rest (every other element loses its digits), all-zero rows, a row of denormals,
+    rows with inf / NaN (the reference's own result, whatever it is, bit for bit), huge and tiny uniform scales, and rows
+    whose sums cancel to a few ulps.  1280 frames through the int8 screening (kind 4) against the oracle, every byte."""
+    rng = np.random.default_rng(5)
+    n = 1280
+    x = F.synth_features(n, 432, seed=31)
+    x[0:64, 7] = 1.0e6                                   # one dominant element
+    x[64:96] = 0.0                                        # empty rows
+    x[96:128] = (rng.standard_normal((32, 432)) * 1e-41).astype(np.float32)   # denormal inputs
+    x[128:160] *= np.float32(1e-12)
+    x[160:192] *= np.float32(1e12)
+    x[192, 3] = np.inf
+    x[193, 5] = -np.inf
+    x[194, 11] = np.nan
+    x[195] = np.float32(3.0e38)
+    x[200:264, :216] = -x[200:264, 216:]                  # (shift/scale sit between this and the layer, so only near-cancelling)
+    x[264:296] = np.round(x[264:296] * 4) / 4             # many exact ties in the products
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    dnn.setInputLayerKernel(4)
+    got, recomputed = dnn.layer0(x)
+    assert recomputed > 0
+    orc = Oracle(net_model_path)
+    with np.errstate(all="ignore"):
+        _, t = orc.calculate(x, taps=True)
+    bad = np.argwhere(got != t["u8_acts"][0])
+    assert bad.size == 0, bad[:8].tolist()
+    dnn.setInputLayerKernel(1)   # and the all-VALU chain kernel agrees with both
+    chain, _ = dnn.layer0(x)
+    assert np.array_equal(chain, got)
+    dnn.delete()
