@@ -99,6 +99,7 @@ SIGNATURES = {
     "fdnn_debug_forward_taps": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_i8p, _c_f32p, _c_u8p, _c_i32p, _c_i32p, _c_f32p, _c_f32p]),
     "fdnn_debug_layer0": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_u8p, C.POINTER(C.c_ulonglong)]),
     "fdnn_model_fuse_giveups": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
+    "fdnn_debug_device_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]),
     "fdnn_profile_begin": (C.c_int, [C.c_void_p]),
     "fdnn_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "fdnn_host_model_load": (C.c_int, [C.c_char_p, C.c_float, C.POINTER(C.c_void_p)]),
@@ -453,6 +454,11 @@ class QuantizedDnn:
         v = C.c_ulonglong(0)
         _check(lib().fdnn_model_fuse_giveups(self.nativeDnnHandle, C.byref(v)))
         return int(v.value)
+
+    def deviceCounters(self, n: int = 32):
+        a = (C.c_ulonglong * n)()
+        _check(lib().fdnn_debug_device_counters(self.nativeDnnHandle, a, n))
+        return list(a)
 
     def profileBegin(self) -> None:
         _check(lib().fdnn_profile_begin(self.nativeDnnHandle))

@@ -48,7 +48,7 @@ struct fdnn_model {
   float *d_w0norm = nullptr;  // [H] ||w_n||_2 rounded up: the node half of the screened layer-0 path's bound
   int8_t *d_w0d = nullptr;    // int8 screening (fdnn_l0s.hip): the layer-0 weights as three int8 digit planes, MFMA fragment order
   float *d_w0stat = nullptr;  // [3][l0_h_ld]: 2^8 / c_n, ||w_n||_2, 2^8 b_n
-  uint16_t *d_lutpair = nullptr;  // the sigmoid table as (round-down, round-up) byte pairs
+  uint32_t *d_lutpair = nullptr;  // the sigmoid table as (round-down, round-up) byte pairs
   unsigned long long *d_l0_stats = nullptr;  // [4] device counters: [1] layer-0 outputs recomputed exactly, [2] fused soft-max tiles that gave up waiting
   int l0_jc = 0, l0_j_pad = 0, l0_h_ld = 0;
   int l0_fma = 0;

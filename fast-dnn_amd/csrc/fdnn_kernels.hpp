@@ -44,7 +44,7 @@ struct L0Params {
   float *xstat;        // [3][n_ld]: 2^16 / c_f, ||x_f||_2 (rounded up), a_f
   const int8_t *wd;    // [chunks][3][h_ld / 32][1024] node planes (model load)
   const float *wstat;  // [3][h_ld]: 2^8 / c_n, ||w_n||_2 (rounded up), 2^8 b_n
-  const uint16_t *lutpair;  // [1283 (+pad)] table bytes on both sides of floor(100 lin) = -641 .. 641
+  const uint32_t *luthalf;  // [kLut2Size (+pad)] the half-step table, 4 bytes per entry: table byte + the 'same byte across the boundary' gate
 };
 constexpr int kL0ScreenCap = 4096;  // listed outputs per tile (25 %); a tile that overflows is recomputed whole
 void launch_l0(const L0Params &p, hipStream_t s);
@@ -53,8 +53,8 @@ void launch_l0(const L0Params &p, hipStream_t s);
 bool l0_split_ok(int D, int H);
 size_t l0_split_plane_bytes(int D, int rows_ld);
 void launch_l0_split(const L0Params &p, hipStream_t s);
-void l0_split_build_weights(const float *w, const float *wnorm, const uint8_t *lut, int H, int D, int h_ld, std::vector<int8_t> *planes,
-                            std::vector<float> *stat, std::vector<uint16_t> *pairs);
+void l0_split_build_weights(const float *w, const float *wnorm, const uint8_t *lut2, int H, int D, int h_ld, std::vector<int8_t> *planes,
+                            std::vector<float> *stat, std::vector<uint32_t> *half);
 int l0_chunk_rows(int D);
 int l0_chain_node_tile();  // 64 (default: no park scratch needed) or 128 (L0Params::park must be allocated)
 void launch_l0_weight_image(const float *w, float *wt, int H, int D, int j_pad, int h_ld, hipStream_t s);

@@ -1199,7 +1199,7 @@ void launch_l0(const L0Params &p, hipStream_t s) {
     const char *e = std::getenv("FDNN_L0_SPLIT_MIN");
     return e ? std::atoi(e) : 640;
   }();
-  const bool can_split = !p.fma && !no_split && !no_screen && (p.kernel == 0 || p.kernel == 4) && !p.tap_lin && p.xd && p.xstat && p.wd && p.wstat && p.lutpair &&
+  const bool can_split = !p.fma && !no_split && !no_screen && (p.kernel == 0 || p.kernel == 4) && !p.tap_lin && p.xd && p.xstat && p.wd && p.wstat && p.luthalf &&
                          p.scr_count && p.scr_list && l0_split_ok(p.D, p.H);
   if (can_split && (p.kernel == 4 || p.n >= split_min)) {
     launch_l0_split(p, s);

@@ -56,7 +56,6 @@ namespace {
 #endif
 constexpr float kU = 5.9604645e-8f;  // 2^-24
 constexpr int kSplitW = 32;          // steps between samples at most (one MFMA = 32 k)
-constexpr int kPairEntries = 2 * kLutHalf + 3;  // table pairs for floor(100 lin) = -641 .. 641
 
 // same workgroup -> tile map as the other layer-0 kernels (fdnn_l0.hip): all node tiles of a frame tile on one XCD
 __device__ __forceinline__ bool split_tile_of_block(int node_tiles, int frame_tiles, int &bx, int &by) {
@@ -74,7 +73,7 @@ __device__ __forceinline__ bool split_tile_of_block(int node_tiles, int frame_ti
 // lane-linear on both sides and its fragment reads are lane-linear too:
 //   xd[chunk][plane][row block of 32][half h][row r][16 bytes]  =  positions 32 chunk + 16 h + 0..15 of row 32 block + r
 constexpr int kDigFrames = 8;
-__global__ __launch_bounds__(256) void l0_digits_kernel(L0Params p, int KC, int J) {
+__global__ __launch_bounds__(256) void l0_digits_kernel(L0Params p, int KC, int J, int JP) {
   extern __shared__ __attribute__((aligned(16))) float dig_smem[];
   const int D = p.D, ld = D + 1;
   float *xs = dig_smem;                      // [8][D + 1]
@@ -124,7 +123,7 @@ __global__ __launch_bounds__(256) void l0_digits_kernel(L0Params p, int KC, int 
       // ||X||_1 <= c_f sum|x| + D  (|X_k| <= |x_k| c_f + 1),  ||X1||_1 <= ||X||_1 / 65536 + 0.502 D
       const float n1X = (cf * s1 * slack + fD) * 1.001f;
       const float n1X1 = n1X * (1.0f / 65536.0f) + 0.502f * fD;
-      const float m = static_cast<float>((J + 31) / 32 + 2);
+      const float m = static_cast<float>(JP / 32 + 1);  // samples per chain (one per chunk) + slack
       const float a_f = kU * (kSplitW + 3) * m * 0.502f * n1X1 + 2.3283064e-10f * (0.5f * n1X + 0.5f * fD) + kU * 256.0f * fD;
       const int f = f0 + row;
       if (f < p.n_ld) {
@@ -144,9 +143,9 @@ __global__ __launch_bounds__(256) void l0_digits_kernel(L0Params p, int KC, int 
       uint32_t w1 = 0, w2 = 0, w3 = 0;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int pp = kc * 32 + hh * 16 + e4 * 4 + e;
-        const int c = (pp >= J) + (pp >= 2 * J) + (pp >= 3 * J), j = pp - c * J;
-        const float v = pp < D ? xs[row * ld + 4 * j + c] : 0.0f;
+        const int pp = kc * 32 + hh * 16 + e4 * 4 + e;  // chain c owns positions c JP .. c JP + J - 1, zeros up to (c + 1) JP
+        const int c = (pp >= JP) + (pp >= 2 * JP) + (pp >= 3 * JP), j = pp - c * JP;
+        const float v = j < J ? xs[row * ld + 4 * j + c] : 0.0f;
         const int X = static_cast<int>(rintf(v * cf));  // |X| <= 8355000 (1 + u) + 0.5
         const int x3 = (X << 24) >> 24, r = (X - x3) >> 8, x2 = (r << 24) >> 24, x1 = (r - x2) >> 8;
         w1 |= static_cast<uint32_t>(x1 & 0xff) << (8 * e);
@@ -172,18 +171,20 @@ __global__ __launch_bounds__(256) void l0_digits_kernel(L0Params p, int KC, int 
 // 32 x 32 MFMA tiles; per 32-position chunk a wave reads 3 frame fragments + 6 node fragments (into the register set
 // the previous chunk is not using) and issues 12 MFMAs.  Registers per lane: P0, P1, P2 and A, 32 each, + 2 x 36 of
 // fragments.  A finished chain's P0 is folded into P1 as 256 P0 (exact in int32 for D <= 496), so no fourth set.
+// Chains are padded to whole chunk pairs, so a chunk never straddles a chain boundary and the chunk body is branch free.
 // Staging: per chunk 24 lane-linear 1-KiB LDS-DMA pieces (3 planes x 4 row blocks, both operands), three per wave,
 // 3-stage ring, one barrier per chunk -- placed between the chunk's two MFMA groups, so that the matrix pipe has work
 // while the waves meet, issue the next pieces and fetch the next fragments.
 constexpr int kSTF = 128, kSTN = 128, kSStage = 24 * 1024, kSStages = 3;
 constexpr int kSRing = kSStage * kSStages;
-constexpr int kSPairOff = kSRing;                    // table pairs: u16 [kPairEntries], 3 KiB
-constexpr int kSStatOff = kSRing + 3072;             // three 1-KiB slots: r_f, ||x||_2, a_f of the tile's 128 frames (512 bytes each + the DMA piece's zero tail)
+constexpr int kSHalfOff = kSRing;                    // half-step table: u32 [kLut2Size] (+ pad), 11 KiB
+constexpr int kSStatOff = kSRing + 11 * 1024;        // three 1-KiB slots: r_f, ||x||_2, a_f of the tile's 128 frames (512 bytes each + the DMA piece's zero tail)
 constexpr int kSLds = kSStatOff + 3 * 1024;
 constexpr int kSTS = kSTN + 16;                      // byte tile row stride
 static_assert(kSTF * kSTS + 16 + 2 * kL0ScreenCap <= kSRing, "epilogue tile and flag list must fit in the dead ring");
+static_assert(4 * kLut2Size <= 11 * 1024, "half-step table area");
 
-__global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, int J) {
+__global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, int CPC) {  // CPC: chunks per chain (even)
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -195,11 +196,19 @@ __global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, in
   if (!split_tile_of_block(node_tiles, frame_tiles, bx, by)) return;
   const int f0 = by * kSTF, n0 = bx * kSTN;
   const int xblocks = p.n_ld >> 5, wblocks = p.h_ld >> 5;
+#ifdef FDNN_L0S_CLK
+  long long tc[12];
+  tc[0] = __builtin_readcyclecounter();
+#define L0S_TS(i) tc[i] = __builtin_readcyclecounter()
+#else
+#define L0S_TS(i)
+#endif
 
-  {  // table pairs and this tile's frame constants into the aux area (LDS-DMA, ahead of the ring)
-    const __amdgpu_buffer_rsrc_t rsrc_pair =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.lutpair), 0, (2 * kPairEntries + 15) & ~15, 0x00020000);
-    if (wave < 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_pair, FDNN_LDS_PTR(smem + kSPairOff + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
+  {  // half-step table and this tile's frame constants into the aux area (LDS-DMA, ahead of the ring): 11 + 3 pieces
+    const __amdgpu_buffer_rsrc_t rsrc_half =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.luthalf), 0, (4 * kLut2Size + 15) & ~15, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_half, FDNN_LDS_PTR(smem + kSHalfOff + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
+    if (wave < 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_half, FDNN_LDS_PTR(smem + kSHalfOff + (8 + wave) * 1024), 16, lane * 16, (8 + wave) * 1024, 0, 0);
     if (wave >= 3 && wave < 6) {  // 128 floats = 512 bytes per constant: lanes 0..31 carry them
       const int q = wave - 3;
       const __amdgpu_buffer_rsrc_t rsrc_st =
@@ -226,29 +235,27 @@ __global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, in
     }
   };
   stage(0, 0);
-  if (KC > 1) stage(1, 1);
-  if (KC > 2) stage(2, 2);
+  stage(1, 1);
+  stage(2, 2);
   asm volatile("" ::: "memory");
 
+  // P0 lives at an offset of 2^30: every partial sum of a chain (|.| <= 2^14 D) is then a positive integer, and |P0 - 2^30|
+  // joins A in ONE instruction (v_sad_u32: unsigned |a - b| + c).  The offset costs nothing at a chain's end: 2^30 << 8 = 0 mod 2^32.
+  constexpr int kP0Off = 0x40000000;
   v16i P0[2], P1[2], P2[2];
-  float A[2][16];
+  uint32_t A[2][16];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      P0[s][r] = 0; P1[s][r] = 0; P2[s][r] = 0;
-      A[s][r] = 0.0f;
+      P0[s][r] = kP0Off; P1[s][r] = 0; P2[s][r] = 0;
+      A[s][r] = 0u;
     }
-  auto sample = [&](int s) {
-    if (FDNN_L0S_DEBUG & 1) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) A[s][r] += fabsf(static_cast<float>(P0[s][r]));
-  };
   auto chain_end = [&](int s) {  // the finished chain's total joins P1 at its weight 2^8 (int32, exact); the next chain starts from zero
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      P1[s][r] += P0[s][r] << 8;
-      P0[s][r] = 0;
+      P1[s][r] += P0[s][r] << 8;  // (the offset drops out: 2^30 << 8 = 2^38)
+      P0[s][r] = kP0Off;
     }
   };
   v4i xa[2][3], wb[2][3][2];  // fragment sets, double buffered over the chunks
@@ -261,87 +268,91 @@ __global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, in
       for (int s = 0; s < 2; ++s) wb[set][pl][s] = *reinterpret_cast<const v4i *>(sb + 12288 + (pl * 4 + wn * 2 + s) * 1024 + lane * 16);
     }
   };
-  // P0 of one chunk for node half s, chain by chain; returns through next_b (wave-uniform)
-  auto p0_step = [&](int kc, int set, int s, int next_b) {
-    const int lo = kc * 32;
-    if (next_b == lo && next_b < p.D) {  // a chain ends exactly at the chunk edge
-      chain_end(s);
-      next_b += J;
-    }
-    const int cut = next_b - lo;
-    if (cut > 0 && cut < 32 && next_b < p.D) {
-      // the chunk straddles a chain boundary: positions below it first (complementary byte masks on the frame fragment)
-      const int keep = min(16, max(0, cut - 16 * h));  // of this lane's 16 positions
-      v4i lo_part, hi_part;
+  // The samples of node half ss (its P0 is complete: one MFMA group ago) go into the issue slots between the MFMAs of
+  // half s -- fenced, or the scheduler runs the 16 vector instructions before or after the MFMAs instead of beside them.
+  auto sample_part = [&](int ss, int r0, int r1, bool on) {
+    if ((FDNN_L0S_DEBUG & 1) || !on) return;
+    // inline asm (no builtin for v_sad_u32; 2.0 is the inline constant 0x40000000 = the offset).  The compiler's hazard
+    // recognizer does not see an MFMA result being read here: P0[ss] was written one whole MFMA group (six MFMAs and a
+    // barrier or the loop edge) ago, far beyond the 18 wait states a 16-pass MFMA needs.
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const int kb = min(4, max(0, keep - 4 * d));
-        const int mask = kb == 4 ? -1 : ((1 << (8 * kb)) - 1);
-        lo_part[d] = xa[set][0][d] & mask;
-        hi_part[d] = xa[set][0][d] & ~mask;
-      }
-      P0[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo_part, wb[set][0][s], P0[s], 0, 0, 0);
-      sample(s);
-      chain_end(s);
-      P0[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi_part, wb[set][0][s], P0[s], 0, 0, 0);
-    } else {
-      P0[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][0], wb[set][0][s], P0[s], 0, 0, 0);
+    for (int r = r0; r < r1; ++r) asm volatile("v_sad_u32 %0, %1, 2.0, %0" : "+v"(A[ss][r]) : "v"(P0[ss][r]));
+  };
+#define FDNN_L0S_FENCE __builtin_amdgcn_sched_barrier(0)
+  auto mfma_group = [&](int set, int s, int ss, bool on) {
+    FDNN_L0S_FENCE;
+    P0[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][0], wb[set][0][s], P0[s], 0, 0, 0);
+    if (FDNN_L0S_DEBUG & 2) {
+      sample_part(ss, 0, 16, on);
+      return;
     }
-  };
-  auto next_boundary = [&](int kc, int next_b) {  // the same bookkeeping as p0_step, for the scalar state
-    const int lo = kc * 32;
-    if (next_b == lo && next_b < p.D) next_b += J;
-    const int cut = next_b - lo;
-    if (cut > 0 && cut < 32 && next_b < p.D) next_b += J;
-    return next_b;
-  };
-  auto low_orders = [&](int set, int s) {
-    if (FDNN_L0S_DEBUG & 2) return;
+    FDNN_L0S_FENCE;
+    sample_part(ss, 0, 3, on);
+    FDNN_L0S_FENCE;
     P1[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][0], wb[set][1][s], P1[s], 0, 0, 0);
+    FDNN_L0S_FENCE;
+    sample_part(ss, 3, 6, on);
+    FDNN_L0S_FENCE;
     P2[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][0], wb[set][2][s], P2[s], 0, 0, 0);
+    FDNN_L0S_FENCE;
+    sample_part(ss, 6, 9, on);
+    FDNN_L0S_FENCE;
     P1[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][1], wb[set][0][s], P1[s], 0, 0, 0);
+    FDNN_L0S_FENCE;
+    sample_part(ss, 9, 12, on);
+    FDNN_L0S_FENCE;
     P2[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][1], wb[set][1][s], P2[s], 0, 0, 0);
+    FDNN_L0S_FENCE;
+    sample_part(ss, 12, 16, on);
+    FDNN_L0S_FENCE;
     P2[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][2], wb[set][0][s], P2[s], 0, 0, 0);
+    FDNN_L0S_FENCE;
   };
 
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // chunk 0 (and the aux pieces before it) landed; chunks 1, 2 may be in flight
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   load_frags(0, 0);
-  int next_b = J;  // position of the next chain boundary
-  auto chunk = [&](int kc, auto set_c) {
+  L0S_TS(1);
+  // One chunk: [MFMA group of node half 0 + the previous chunk's samples of half 1] -- meet, refill, next fragments --
+  // [MFMA group of half 1 + this chunk's samples of half 0].  At the first chunk of a later chain the finished chain's P0
+  // joins P1: half 0 before its MFMA, half 1 after its last sample.
+  auto chunk = [&](int kc, auto set_c, auto first_c, bool chain_start) {
     constexpr int set = decltype(set_c)::value;  // (compile time: the fragment sets are registers)
-    // ---- first MFMA group: node half 0
-    p0_step(kc, set, 0, next_b);
-    low_orders(set, 0);
-    // ---- meet: chunk kc + 1 landed for everyone, everyone has read chunk kc (its fragments are in registers)
+    constexpr bool first = decltype(first_c)::value;
+    if (chain_start) chain_end(0);  // (wave-uniform, three times per tile)
+    mfma_group(set, 0, 1, !first);
     if (kc + 1 < KC) {
       if (kc + 2 < KC)
         asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");  // my three pieces of chunk kc + 2 may still be in flight
       else
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();  // chunk kc + 1 landed for everyone, everyone has read chunk kc (its fragments are in registers)
       asm volatile("" ::: "memory");
       if (kc + 3 < KC && !(FDNN_L0S_DEBUG & 8)) stage(kc + 3, kc % 3);  // into the buffer chunk kc has just left
       load_frags((kc + 1) % 3, set ^ 1);
     }
-    // ---- second MFMA group: node half 1; the samples of half 0 ride along
-    p0_step(kc, set, 1, next_b);
-    sample(0);
-    low_orders(set, 1);
-    sample(1);
-    next_b = next_boundary(kc, next_b);
+    if (chain_start) chain_end(1);
+    mfma_group(set, 1, 0, true);
   };
-  for (int kc = 0; kc < KC; kc += 2) {
-    chunk(kc, std::integral_constant<int, 0>{});
-    if (kc + 1 < KC) chunk(kc + 1, std::integral_constant<int, 1>{});
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  chunk(0, C0{}, std::true_type{}, false);
+  chunk(1, C1{}, std::false_type{}, false);
+  for (int kc = 2, in_chain = 2; kc < KC; kc += 2, in_chain += 2) {  // (KC and CPC are even)
+    const bool chain_start = in_chain == CPC;
+    if (chain_start) in_chain = 0;
+    chunk(kc, C0{}, std::false_type{}, chain_start);
+    chunk(kc + 1, C1{}, std::false_type{}, false);
   }
-  chain_end(0);  // the last chain (its final value was sampled above)
+  sample_part(1, 0, 16, true);  // (half 1's samples trail by one group; the last MFMA group is long done: the epilogue's barrier follows)
+  chain_end(0);
   chain_end(1);
+  L0S_TS(2);
 
   // ------------------------------------------------------------ epilogue
   __syncthreads();  // the ring is dead: byte tile + flag list
-  const uint16_t *pair_s = reinterpret_cast<const uint16_t *>(smem + kSPairOff);
+  const char *half_b = smem + kSHalfOff + 4 * kLut2Half;  // entry 0 of the half-step table
   const float *rf_s = reinterpret_cast<const float *>(smem + kSStatOff);
   const float *xn_s = rf_s + 256, *af_s = rf_s + 512;
   uint8_t *tile = reinterpret_cast<uint8_t *>(smem);
@@ -350,56 +361,66 @@ __global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, in
   if (tid == 0) *scr_n = 0;
   const float fD = static_cast<float>(p.D);
   const float c2 = 1.001f * (0.5f * fD * fD + 2.0f * fD) * kU;  // second order in u over the D steps (as the fp32 screen)
-  const float kA = 256.0f * 1.002f * kU * (kSplitW + 3);        // (x 256: sigma below is 2^-8 sigma*)
-  const float kS = 1.002f * kU * (kSplitW / 2 + 2 + c2);
+  // everything below works on t = 100 lin: sig100 = 100 sigma, and the bound's constants carry the 100.001 / 100 = 1.00001
+  const float kA = 1.00001f * 256.0f * 1.002f * kU * (kSplitW + 3);  // (x 256: sigma is 2^-8 sigma*)
+  const float kS = 100.001f * 1.002f * kU * (kSplitW / 2 + 2 + c2);
   // this lane's node constants (two columns)
-  float bias2[2], rn2[2], kSw2[2], bn2[2], eb2[2];
+  float bias100[2], rn100[2], kSw2[2], bn2[2], eb2[2];
   bool node_in[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int node = n0 + wn * 64 + s * 32 + l32;
     node_in[s] = node < p.H;
-    bias2[s] = node_in[s] ? p.bias[node] : 0.0f;
-    rn2[s] = node_in[s] ? p.wstat[node] : 0.0f;
+    const float b = node_in[s] ? p.bias[node] : 0.0f;
+    bias100[s] = 100.0f * b;
+    rn100[s] = 100.0f * (node_in[s] ? p.wstat[node] : 0.0f);
     kSw2[s] = kS * (node_in[s] ? p.wstat[p.h_ld + node] : 0.0f);
-    bn2[s] = node_in[s] ? p.wstat[2 * p.h_ld + node] : 0.0f;
-    eb2[s] = 10.0f * kU * fabsf(bias2[s]);
+    bn2[s] = 1.00001f * (node_in[s] ? p.wstat[2 * p.h_ld + node] : 0.0f);
+    eb2[s] = 100.001f * 10.0f * kU * fabsf(b);
+  }
+  // which of this lane's 32 outputs exist (frame inside the batch, node inside the layer): applied to the flag bits at the end
+  uint32_t valid = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const bool row_in = f0 + wf * 32 + 8 * (r >> 2) + 4 * h + (r & 3) < p.n;
+    valid |= (row_in && node_in[0] ? 1u : 0u) << r;
+    valid |= (row_in && node_in[1] ? 1u : 0u) << (16 + r);
   }
   uint32_t scr_mask = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = wf * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
     const float rf = rf_s[row], xn = xn_s[row], af = af_s[row];
-    const bool row_in = f0 + row < p.n;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      // V = 2^-8 (P1' + 2^-8 P2), P1' = 256 P0 + P1 in int32; sig = 2^24 / (c_f c_n)
+      // V = 2^-8 (P1' + 2^-8 P2), P1' = 256 P0 + P1 in int32; sig = 100 * 2^24 / (c_f c_n);  t ~ 100 lin (dnn.h:37)
       const float v = fmaf(static_cast<float>(P2[s][r]), 0.00390625f, static_cast<float>(P1[s][r]));
-      const float sig = rf * rn2[s];
-      const float lin = fmaf(v, sig, bias2[s]);
-      const float t = lin * 100.0f;
-      const float fl = floorf(t), frac = t - fl;  // exact below 2^23
-      // the table bytes on both sides of t: entries round-down and round-up of QuantizedSigmoid::get (dnn.h:36-43)
-      const int pi = static_cast<int>(__builtin_amdgcn_fmed3f(fl, -641.0f, 641.0f)) + 641;  // (a NaN picks an end; flagged below)
-      const uint32_t pr = pair_s[pi];
-      // round(): half away from zero (dnn.h:37)
-      const bool up = (frac > 0.5f) | ((frac == 0.5f) & (t >= 0.0f));
-      const uint32_t lo_b = pr & 0xffu, hi_b = pr >> 8;
-      const uint32_t act = up ? hi_b : lo_b;
-      tile[row * kSTS + wn * 64 + s * 32 + l32] = static_cast<uint8_t>(act);
+      const float sig = rf * rn100[s];
+      const float t = fmaf(v, sig, bias100[s]);
+      // QuantizedSigmoid::get through the half-step table (fdnn_model.cpp): index trunc(2 t), clamped; the entry carries the
+      // table byte and, in its upper half, a gate: 0.25f where the byte on the other side of the nearest half-integer is
+      // the same, else 0
+      const int u = max(-kLut2Half, min(kLut2Half, static_cast<int>(t + t)));  // (v_cvt_i32_f32 truncates, saturates, NaN -> 0)
+      const uint32_t ent = *reinterpret_cast<const uint32_t *>(half_b + 4 * u);
+      tile[row * kSTS + wn * 64 + s * 32 + l32] = static_cast<uint8_t>(ent);
       if (!(FDNN_L0S_DEBUG & 4)) {
-        const float E = fmaf(sig, fmaf(kA, A[s][r], af + bn2[s]), fmaf(kSw2[s], xn, eb2[s]));
-        const float Dd = fmaf(100.001f, E, fabsf(t) * (12.0f * kU)) + 1e-30f;
-        const bool near = !(fabsf(frac - 0.5f) > Dd) & !(fabsf(t) - Dd >= 641.0f);  // written so that a NaN flags
-        const bool differ = (lo_b != hi_b) | !(Dd < 0.25f);                          // several boundaries in reach: always recompute
-        // x86 float -> int turns NaN and |t| >= 2^31 into INT_MIN (entry 0 after the clamp, lut_index): anything near that takes the exact path
-        const bool huge = !(fabsf(t) < 1.0e9f);
-        const bool flag = ((near & differ) | huge) & row_in & node_in[s];
-        scr_mask |= flag ? (1u << (16 * s + r)) : 0u;
+        const float e = __builtin_amdgcn_fractf(t) - 0.5f;  // against the half-integer above floor(t): the nearest one
+        const float Dd = fmaf(fabsf(t), 12.0f * kU, fmaf(sig, fmaf(kA, static_cast<float>(A[s][r]), af + bn2[s]), fmaf(kSw2[s], xn, eb2[s]))) + 1e-30f;
+        // flagged: a half-integer within Dd of t, AND (different bytes on its two sides OR Dd >= 0.25: several boundaries in
+        // reach), AND not both clamped to the same end of the table (|t| - Dd >= 641)  ==  max(|e|, gate, |t| - 641) <= Dd,
+        // written so that a NaN flags.  x86 float -> int turns NaN and |t| >= 2^31 into INT_MIN (entry 0 after the clamp,
+        // lut_index): anything near that takes the exact path as well.
+        const float gate = __builtin_bit_cast(float, ent & 0xffff0000u);
+        const float m = fmaxf(fmaxf(fabsf(e), gate), fabsf(t) - 641.0f);
+        const bool flag = !(m > Dd) | !(fabsf(t) < 1.0e9f);
+        if (__builtin_amdgcn_ballot_w64(flag)) scr_mask |= flag ? (1u << (16 * s + r)) : 0u;  // (rare: one output in 300)
       }
     }
   }
+  scr_mask &= valid;
+  L0S_TS(3);
   __syncthreads();  // (scr_n = 0 is visible; the byte tile is complete)
+  L0S_TS(4);
   {  // the wave reserves room for all its flagged outputs with ONE LDS atomic, every lane then writes its own entries
     const int mine = __popc(scr_mask);
     int incl = mine;
@@ -440,33 +461,50 @@ __global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, in
     const uint32_t listed = min(cnt, static_cast<uint32_t>(kL0ScreenCap));
     for (uint32_t i = tid; i < listed; i += 512) p.scr_list[static_cast<size_t>(tile_id) * kL0ScreenCap + i] = scr_l[i];
   }
+#ifdef FDNN_L0S_CLK
+  L0S_TS(5);
+  if (p.scr_stats && lane == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 + 3)) {
+    unsigned long long *o = p.scr_stats + 4 + (blockIdx.x == 0 ? 0 : 12);
+    for (int i = 0; i < 6; ++i) o[i] = static_cast<unsigned long long>(tc[i] - tc[0]);
+  }
+#endif
 #endif
 }
 
 }  // namespace
 
-// D >= 128: a 32-position chunk meets at most one chain boundary; D <= 496: 256 P0 + P1 stays inside int32 (2^22 D + 2^15 D < 2^31)
-// and the pre-pass rows fit its LDS
-bool l0_split_ok(int D, int H) { return D >= 128 && D <= 496 && (D & 3) == 0 && (H & 15) == 0; }
-int l0_split_chunks(int D) { return (D + 31) / 32; }
+// D <= 496: 256 P0 + P1 stays inside int32 (2^22 D + 2^15 D < 2^31) and the pre-pass rows fit its LDS
+bool l0_split_ok(int D, int H) { return D >= 64 && D <= 496 && (D & 3) == 0 && (H & 15) == 0; }
+// chains are padded to whole chunk PAIRS (the kernel alternates two fragment register sets): 432 -> 4 x 128 positions, 16 chunks
+int l0_split_chain_pad(int D) { return (D / 4 + 63) / 64 * 64; }
+int l0_split_chunks(int D) { return 4 * l0_split_chain_pad(D) / 32; }
 size_t l0_split_plane_bytes(int D, int rows_ld) { return static_cast<size_t>(l0_split_chunks(D)) * 3 * static_cast<size_t>(rows_ld / 32) * 1024; }
-size_t l0_split_pair_bytes() { return (2 * kPairEntries + 15) & ~size_t(15); }
+size_t l0_split_half_bytes() { return (4 * size_t(kLut2Size) + 15) & ~size_t(15); }
 
 // Model load: the node half.  w [H][D] fp32 -> digit planes in fragment order + per-node constants {r_n, ||w||_2 (the
 // caller's), b_n}, and the table as pairs.  Host code, double arithmetic: w c_n is exact in double, so |w c_n - W| <= 0.5.
-void l0_split_build_weights(const float *w, const float *wnorm, const uint8_t *lut, int H, int D, int h_ld, std::vector<int8_t> *planes,
-                            std::vector<float> *stat, std::vector<uint16_t> *pairs) {
-  const int J = D / 4;
+void l0_split_build_weights(const float *w, const float *wnorm, const uint8_t *lut2, int H, int D, int h_ld, std::vector<int8_t> *planes,
+                            std::vector<float> *stat, std::vector<uint32_t> *half) {
+  const int J = D / 4, JP = l0_split_chain_pad(D);
   planes->assign(l0_split_plane_bytes(D, h_ld), 0);
   stat->assign(static_cast<size_t>(3) * h_ld, 0.0f);
-  pairs->assign(l0_split_pair_bytes() / 2, 0);
-  for (int i = 0; i < kPairEntries; ++i) {  // entry i: floor(100 lin) = i - 641; bytes lut[clamp(.)] and lut[clamp(. + 1)]
-    const int lo = std::max(-kLutHalf, std::min(kLutHalf, i - 641)), hi = std::max(-kLutHalf, std::min(kLutHalf, i - 640));
-    (*pairs)[i] = static_cast<uint16_t>(lut[lo + kLutHalf] | (lut[hi + kLutHalf] << 8));
+  // The blob's half-step table (index trunc(2 t), fdnn_model.cpp) widened to 4 bytes per entry: the table byte, and in the
+  // upper half the float bits of the gate -- 0.25f where the entry on the other side of the nearest half-integer
+  // (|u| ^ 1 with the sign of u; both neighbours for u = 0) holds the same byte, else 0.
+  half->assign(l0_split_half_bytes() / 4, 0);
+  auto at = [&](int u) { return lut2[std::max(-kLut2Half, std::min(kLut2Half, u)) + kLut2Half]; };
+  for (int u = -kLut2Half; u <= kLut2Half; ++u) {
+    const int mag = u < 0 ? -u : u;
+    bool same;
+    if (u == 0)
+      same = at(0) == at(1) && at(0) == at(-1);
+    else
+      same = at(u) == at(u < 0 ? -(mag ^ 1) : (mag ^ 1));
+    (*half)[u + kLut2Half] = at(u) | (same ? 0x3e800000u : 0u);  // 0.25f = 0x3e800000
   }
   const size_t blocks = static_cast<size_t>(h_ld / 32);
   const double u = std::ldexp(1.0, -24);
-  const double m = static_cast<double>((J + 31) / 32 + 2);
+  const double m = static_cast<double>(JP / 32 + 1);
   for (int n = 0; n < H; ++n) {
     const float *row = w + static_cast<size_t>(n) * D;
     double mx = 0.0;
@@ -479,8 +517,9 @@ void l0_split_build_weights(const float *w, const float *wnorm, const uint8_t *l
     const bool degenerate = bad || mx > 1.0e18 || (mx != 0.0 && mx < 1.0e-18);
     const float cn = (mx == 0.0 || degenerate) ? 1.0f : static_cast<float>(8355000.0 / mx);
     double n1W = 0.0, n1W2 = 0.0, n1W3 = 0.0;
-    for (int pp = 0; pp < D; ++pp) {
-      const int c = pp / J, j = pp - c * J, k = 4 * j + c;
+    for (int pp = 0; pp < 4 * JP; ++pp) {
+      const int c = pp / JP, j = pp - c * JP, k = 4 * j + c;
+      if (j >= J) continue;  // (pad positions stay zero)
       const long W = degenerate ? 0 : std::lrint(static_cast<double>(row[k]) * static_cast<double>(cn));
       n1W += static_cast<double>(W < 0 ? -W : W);
       const int x3 = static_cast<int8_t>(W & 0xff), r = static_cast<int>((W - x3) >> 8), x2 = static_cast<int8_t>(r & 0xff), x1 = (r - x2) >> 8;
@@ -507,7 +546,7 @@ void l0_split_build_weights(const float *w, const float *wnorm, const uint8_t *l
 
 // pre-pass + matrix kernel; the caller (fdnn_l0.hip: launch_l0) follows with l0_fix_kernel on the same tile lists
 void launch_l0_split(const L0Params &p, hipStream_t s) {
-  const int KC = l0_split_chunks(p.D), J = p.D / 4;
+  const int KC = l0_split_chunks(p.D), J = p.D / 4, JP = l0_split_chain_pad(p.D);
   static std::atomic<unsigned long long> attr_set{0};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -519,8 +558,8 @@ void launch_l0_split(const L0Params &p, hipStream_t s) {
   }
   const int frame_tiles = (p.n_rows + kSTF - 1) / kSTF, node_tiles = p.h_ld / kSTN;
   const int dig_rows = frame_tiles * kSTF;  // every row a matrix tile will read (<= n_ld)
-  hipLaunchKernelGGL(l0_digits_kernel, dim3(dig_rows / kDigFrames), dim3(256), dig_lds, s, p, KC, J);
-  hipLaunchKernelGGL(l0_split_kernel, dim3(static_cast<unsigned>(node_tiles) * ((frame_tiles + 7) / 8) * 8), dim3(512), kSLds, s, p, KC, J);
+  hipLaunchKernelGGL(l0_digits_kernel, dim3(dig_rows / kDigFrames), dim3(256), dig_lds, s, p, KC, J, JP);
+  hipLaunchKernelGGL(l0_split_kernel, dim3(static_cast<unsigned>(node_tiles) * ((frame_tiles + 7) / 8) * 8), dim3(512), kSLds, s, p, KC, JP / 32);
 }
 
 }  // namespace fdnn

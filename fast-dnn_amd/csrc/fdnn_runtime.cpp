@@ -121,17 +121,17 @@ int build_l0_image(fdnn_model *m) {
     if (fdnn::l0_split_ok(h.in_dim, h.hidden)) {  // the node half of the int8 screening (fdnn_l0s.hip): digit planes + constants
       std::vector<int8_t> planes;
       std::vector<float> stat;
-      std::vector<uint16_t> pairs;
-      fdnn::l0_split_build_weights(w0, wn.data(), m->hm.blob.data() + h.off_lut, h.hidden, h.in_dim, m->l0_h_ld, &planes, &stat, &pairs);
-      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_lutpair), sizeof(uint16_t) * pairs.size()));
-      HIP_TRY(hipMemcpy(m->d_lutpair, pairs.data(), sizeof(uint16_t) * pairs.size(), hipMemcpyHostToDevice));
+      std::vector<uint32_t> pairs;
+      fdnn::l0_split_build_weights(w0, wn.data(), m->hm.blob.data() + h.off_lut2, h.hidden, h.in_dim, m->l0_h_ld, &planes, &stat, &pairs);
+      HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_lutpair), sizeof(uint32_t) * pairs.size()));
+      HIP_TRY(hipMemcpy(m->d_lutpair, pairs.data(), sizeof(uint32_t) * pairs.size(), hipMemcpyHostToDevice));
       HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_w0d), planes.size()));
       HIP_TRY(hipMemcpy(m->d_w0d, planes.data(), planes.size(), hipMemcpyHostToDevice));
       HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_w0stat), sizeof(float) * stat.size()));
       HIP_TRY(hipMemcpy(m->d_w0stat, stat.data(), sizeof(float) * stat.size(), hipMemcpyHostToDevice));
     }
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_l0_stats), 4 * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(m->d_l0_stats, 0, 4 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_l0_stats), 32 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(m->d_l0_stats, 0, 32 * sizeof(unsigned long long)));
   }
   HIP_TRY(hipDeviceSynchronize());
   return FDNN_OK;
@@ -333,7 +333,7 @@ void run_layer0(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) 
   l0.xstat = c->d_xstat;
   l0.wd = m->d_w0d;
   l0.wstat = m->d_w0stat;
-  l0.lutpair = m->d_lutpair;
+  l0.luthalf = m->d_lutpair;
   l0.j_pad = m->l0_j_pad;
   l0.jc = m->l0_jc;
   l0.n_ld = c->xt_ld;
@@ -1025,6 +1025,15 @@ int fdnn_debug_production_acc_out(fdnn_model *m, const float *x, int n, int stri
   fdnn_ctx_free(c);
   if (rc) return rc;
   if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("acc probe: ") + hipGetErrorString(e));
+  return FDNN_OK;
+}
+
+int fdnn_debug_device_counters(fdnn_model *m, unsigned long long *out, int n) {  // raw device counter words (kernel clock stamps of timing builds live at [4..])
+  if (!m || !out || n < 0 || n > 32) return fail(FDNN_E_ARG, "bad argument");
+  if (!m->d_l0_stats) return fail(FDNN_E_STATE, "no counters");
+  DeviceGuard g(m->device);
+  const hipError_t e = hipMemcpy(out, m->d_l0_stats, sizeof(unsigned long long) * size_t(n), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("device counters: ") + hipGetErrorString(e));
   return FDNN_OK;
 }
 

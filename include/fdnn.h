@@ -265,6 +265,9 @@ FDNN_API int fdnn_debug_layer0(fdnn_model *m, const float *x, int n, uint8_t *u8
  * milliseconds late.  *tiles = how many tiles that has happened to on this model since load (0 in a healthy setup).
  * SoftMax::apply, src/cpp/dnn.cc:534-544, is what is being computed. */
 FDNN_API int fdnn_model_fuse_giveups(fdnn_model *m, unsigned long long *tiles);
+/* The model's raw device counter words, n <= 32 ([1] layer-0 outputs recomputed, [2] fused soft-max give-ups; kernel clock
+ * stamps of timing builds from [4]).  Measurements only. */
+FDNN_API int fdnn_debug_device_counters(fdnn_model *m, unsigned long long *out, int n);
 
 /* ------------------------------------------------------------------ per-kernel timing (bench / profiling only)
  * Between begin and end every kernel launch of this model is bracketed by HIP

@@ -18,3 +18,9 @@ for rep in range(3):
     torch.cuda.synchronize()
     prof = dnn.profileEnd()
     print({k: round(v["ms"] / 40 * 1e3, 1) for k, v in prof.items() if v["launches"]}, flush=True)
+if os.environ.get("CLK"):
+    c = dnn.deviceCounters(32)
+    for name, base in (("block 0 wave 0", 4), ("mid block wave 0", 16)):
+        t = c[base:base + 12]
+        print(name, "cycles: prologue", t[1], "k-loop end", t[2], "epilogue math", t[3], "sync", t[4], "end", t[5],
+              "| chunk 6: group 1", t[7] - t[6], "wait+barrier", t[8] - t[7], "dma issue", t[9] - t[8], "frag reads", t[10] - t[9], "group 2", t[11] - t[10])
