@@ -83,6 +83,9 @@ struct fdnn_ctx {
   uint16_t *d_scr_list = nullptr;   // [tiles][kL0ScreenCap]
   int8_t *d_xd = nullptr;           // int8 screening: the frames' digit planes [chunks][3][xt_ld / 32][1024]
   float *d_xstat = nullptr;         // [3][xt_ld] row constants written by the pre-pass
+  uint2 *d_glist = nullptr;         // int8 screening: {frame, node} of the launch's flagged outputs
+  uint32_t *d_glist_count = nullptr;  // [2] entries appended, tiles in the whole-tile path
+  int glist_cap = 0;
   int8_t *d_act[2] = {nullptr, nullptr};  // [n_pad][act_ld] ping/pong, s8 = u8-128
   float *d_out = nullptr;         // [n][O]
   float *d_partial = nullptr;     // [rows_pad/64][n_pad]

@@ -44,6 +44,9 @@ struct L0Params {
   float *xstat;        // [3][n_ld]: 2^16 / c_f, ||x_f||_2 (rounded up), a_f
   const int8_t *wd;    // [chunks][3][h_ld / 32][1024] node planes (model load)
   const float *wstat;  // [3][h_ld]: 2^8 / c_n, ||w_n||_2 (rounded up), 2^8 b_n
+  uint2 *glist;        // [glist_cap] {frame, node} of every flagged output of the launch (tiles append with one atomic each)
+  uint32_t *glist_count;  // [2]: entries appended; tiles that overflowed into the whole-tile path.  Zeroed by the pre-pass
+  int glist_cap;
   const uint32_t *luthalf;  // [kLut2Size (+pad)] the half-step table, 4 bytes per entry: table byte + the 'same byte across the boundary' gate
 };
 constexpr int kL0ScreenCap = 4096;  // listed outputs per tile (25 %); a tile that overflows is recomputed whole

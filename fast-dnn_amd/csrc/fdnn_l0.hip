@@ -1021,6 +1021,48 @@ __device__ __forceinline__ float quad_bcast(float v) {
 // and scale applied, w) -- and each step's quad is then handed round with quad broadcasts, chain c keeping element c.
 // (One lane per output reading 16 bytes of its own rows per load is address-processing bound: every (output, k-quad) is
 // its own 16-byte segment -- 66 us for 0.4 % of the outputs.)
+// One listed output, four lanes = four chains (lane c is chain c; all four lanes of a quad must call this together).
+__device__ __forceinline__ void fix_one_output(const L0Params &p, const float *sh_s, const float *sc_s, int f, int node, bool live, int c, int quads) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const float *xr = p.x + static_cast<size_t>(live ? f : 0) * p.D, *wr = p.w + static_cast<size_t>(live ? node : 0) * p.D;
+  float acc = 0.0f;
+  // twelve k-steps per round: the three quads per lane (and operand) are all requested before the first is used --
+  // with one quad in flight per lane the walk is a chain of 27 L2 round trips
+  for (int q0 = 0; q0 < quads; q0 += 12) {
+    v4f xq[3], wq[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int q = min(q0 + 4 * b + c, quads - 1);  // (a clamped quad is never consumed: its step is skipped below)
+      xq[b] = *reinterpret_cast<const v4f *>(xr + 4 * q);
+      wq[b] = *reinterpret_cast<const v4f *>(wr + 4 * q);
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int q = min(q0 + 4 * b + c, quads - 1);
+      xq[b] = (xq[b] + *reinterpret_cast<const v4f *>(sh_s + 4 * q)) * *reinterpret_cast<const v4f *>(sc_s + 4 * q);  // add, then multiply
+    }
+#define FDNN_FIX_STEP(B, S)                                                                                                   \
+  if (q0 + 4 * B + S < quads) {                                                                                               \
+    const float x0 = quad_bcast<S>(xq[B].x), x1 = quad_bcast<S>(xq[B].y), x2 = quad_bcast<S>(xq[B].z), x3 = quad_bcast<S>(xq[B].w); \
+    const float w0 = quad_bcast<S>(wq[B].x), w1 = quad_bcast<S>(wq[B].y), w2 = quad_bcast<S>(wq[B].z), w3 = quad_bcast<S>(wq[B].w); \
+    const float xs = c == 0 ? x0 : c == 1 ? x1 : c == 2 ? x2 : x3;                                                            \
+    const float wv = c == 0 ? w0 : c == 1 ? w1 : c == 2 ? w2 : w3;                                                            \
+    const float pr = xs * wv; /* this file is compiled -ffp-contract=off: product and sum round separately */                \
+    acc = acc + pr;           /* (dnn.cc:233-238) */                                                                          \
+  }
+    FDNN_FIX_STEP(0, 0) FDNN_FIX_STEP(0, 1) FDNN_FIX_STEP(0, 2) FDNN_FIX_STEP(0, 3)
+    FDNN_FIX_STEP(1, 0) FDNN_FIX_STEP(1, 1) FDNN_FIX_STEP(1, 2) FDNN_FIX_STEP(1, 3)
+    FDNN_FIX_STEP(2, 0) FDNN_FIX_STEP(2, 1) FDNN_FIX_STEP(2, 2) FDNN_FIX_STEP(2, 3)
+#undef FDNN_FIX_STEP
+  }
+  const float c0 = quad_bcast<0>(acc), c1 = quad_bcast<1>(acc), c2 = quad_bcast<2>(acc), c3 = quad_bcast<3>(acc);
+  if (live && c == 0) {
+    const float lin = ((c0 + c1) + (c2 + c3)) + p.bias[node];  // horizontalSum (dnn.cc:168-172), AddBias
+    if (p.tap_lin) p.tap_lin[static_cast<size_t>(f) * p.H + node] = lin;
+    p.act_out[static_cast<size_t>(f) * p.act_ld + node] = static_cast<int8_t>(p.lut[lut_index(lin)]);
+  }
+}
+
 #ifndef FDNN_L0_FIX_THREADS
 #define FDNN_L0_FIX_THREADS 512  // 128 outputs per pass: 40.1 us against 42.6 (256), 45.4 (128), 71 (1024) for 82 000 outputs
 #endif
@@ -1044,59 +1086,65 @@ __global__ __launch_bounds__(kFixThreads) void l0_fix_kernel(L0Params p, int TF)
     sc_s[k] = p.scale[k];
   }
   __syncthreads();
-  int done = 0;
   for (int base = 0; base < total; base += kFixThreads / 4) {  // (uniform trip count: the quad broadcasts need all four lanes present)
     const int o = base + (tid >> 2);
     const bool valid = o < total;
     const int local = valid ? (all ? o : p.scr_list[static_cast<size_t>(tile_id) * kL0ScreenCap + o]) : 0;
     const int f = f0 + local / TN, node = n0 + local % TN;
-    const bool live = valid && f < p.n && node < p.H;
-    const float *xr = p.x + static_cast<size_t>(live ? f : 0) * p.D, *wr = p.w + static_cast<size_t>(live ? node : 0) * p.D;
-    float acc = 0.0f;
-    // twelve k-steps per round: the three quads per lane (and operand) are all requested before the first is used --
-    // with one quad in flight per lane the walk is a chain of 27 L2 round trips
-    for (int q0 = 0; q0 < quads; q0 += 12) {
-      v4f xq[3], wq[3];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        const int q = min(q0 + 4 * b + c, quads - 1);  // (a clamped quad is never consumed: its step is skipped below)
-        xq[b] = *reinterpret_cast<const v4f *>(xr + 4 * q);
-        wq[b] = *reinterpret_cast<const v4f *>(wr + 4 * q);
-      }
-#pragma unroll
-      for (int b = 0; b < 3; ++b) {
-        const int q = min(q0 + 4 * b + c, quads - 1);
-        xq[b] = (xq[b] + *reinterpret_cast<const v4f *>(sh_s + 4 * q)) * *reinterpret_cast<const v4f *>(sc_s + 4 * q);  // add, then multiply
-      }
-#define FDNN_FIX_STEP(B, S)                                                                                                   \
-  if (q0 + 4 * B + S < quads) {                                                                                               \
-    const float x0 = quad_bcast<S>(xq[B].x), x1 = quad_bcast<S>(xq[B].y), x2 = quad_bcast<S>(xq[B].z), x3 = quad_bcast<S>(xq[B].w); \
-    const float w0 = quad_bcast<S>(wq[B].x), w1 = quad_bcast<S>(wq[B].y), w2 = quad_bcast<S>(wq[B].z), w3 = quad_bcast<S>(wq[B].w); \
-    const float xs = c == 0 ? x0 : c == 1 ? x1 : c == 2 ? x2 : x3;                                                            \
-    const float wv = c == 0 ? w0 : c == 1 ? w1 : c == 2 ? w2 : w3;                                                            \
-    const float pr = xs * wv; /* this file is compiled -ffp-contract=off: product and sum round separately */                \
-    acc = acc + pr;           /* (dnn.cc:233-238) */                                                                          \
+    fix_one_output(p, sh_s, sc_s, f, node, valid && f < p.n && node < p.H, c, quads);
   }
-      FDNN_FIX_STEP(0, 0) FDNN_FIX_STEP(0, 1) FDNN_FIX_STEP(0, 2) FDNN_FIX_STEP(0, 3)
-      FDNN_FIX_STEP(1, 0) FDNN_FIX_STEP(1, 1) FDNN_FIX_STEP(1, 2) FDNN_FIX_STEP(1, 3)
-      FDNN_FIX_STEP(2, 0) FDNN_FIX_STEP(2, 1) FDNN_FIX_STEP(2, 2) FDNN_FIX_STEP(2, 3)
-#undef FDNN_FIX_STEP
-    }
-    const float c0 = quad_bcast<0>(acc), c1 = quad_bcast<1>(acc), c2 = quad_bcast<2>(acc), c3 = quad_bcast<3>(acc);
-    if (live && c == 0) {
-      const float lin = ((c0 + c1) + (c2 + c3)) + p.bias[node];  // horizontalSum (dnn.cc:168-172), AddBias
-      if (p.tap_lin) p.tap_lin[static_cast<size_t>(f) * p.H + node] = lin;
-      p.act_out[static_cast<size_t>(f) * p.act_ld + node] = static_cast<int8_t>(p.lut[lut_index(lin)]);
-      ++done;
-    }
-  }
-  (void)done;
   __syncthreads();  // every thread has read the count and its entries
   if (tid == 0) {
     p.scr_count[tile_id] = 0;  // ready for the next launch
     // ONE atomic per tile (one per recomputed output -- 80 000 on one address -- cost more than the recomputation)
     if (p.scr_stats) atomicAdd(p.scr_stats + 1, static_cast<unsigned long long>(all ? TF * TN : count));
   }
+}
+
+// Round 4 (int8 screening): the flagged outputs of ALL tiles in one list (the matrix kernel reserves room with one global
+// atomic per tile), recomputed 128 per workgroup pass.  With a workgroup per tile every workgroup ran one pass for its
+// ~70 outputs -- 1280 latency-bound passes, 2.5 rounds of them on the chip; the same outputs are 570 full passes, all
+// resident at once.  A tile whose own count overflowed the per-tile list (> 25 % flagged) is still recomputed whole.
+__global__ __launch_bounds__(kFixThreads) void l0_fix_list_kernel(L0Params p, int tiles) {
+  constexpr int TN = 128, TF = 128;
+  const int tid = threadIdx.x, c = tid & 3;
+  const int quads = p.D / 4;
+  extern __shared__ __attribute__((aligned(16))) float fix_smem[];  // shift[D], scale[D]
+  float *sh_s = fix_smem, *sc_s = fix_smem + p.D;
+  const uint32_t total = min(p.glist_count[0], static_cast<uint32_t>(p.glist_cap));
+  const bool any_overflow = p.glist_count[1] != 0u;  // some tile kept its outputs to itself (scr_count / whole-tile path)
+  if (static_cast<uint32_t>(blockIdx.x) * (kFixThreads / 4) >= total && !any_overflow) return;
+  for (int k = tid; k < p.D; k += kFixThreads) {
+    sh_s[k] = p.shift[k];
+    sc_s[k] = p.scale[k];
+  }
+  __syncthreads();
+  for (uint32_t base = blockIdx.x * (kFixThreads / 4); base < total; base += gridDim.x * (kFixThreads / 4)) {
+    const uint32_t o = base + (tid >> 2);
+    const bool valid = o < total;
+    const uint2 ent = valid ? p.glist[o] : make_uint2(0u, 0u);
+    fix_one_output(p, sh_s, sc_s, static_cast<int>(ent.x), static_cast<int>(ent.y), valid && static_cast<int>(ent.x) < p.n && static_cast<int>(ent.y) < p.H, c, quads);
+  }
+  if (any_overflow) {
+    const int node_tiles = (p.H + TN - 1) / TN;
+    for (int tile_id = blockIdx.x; tile_id < tiles; tile_id += gridDim.x) {
+      const uint32_t count = p.scr_count[tile_id];
+      if (count == 0) continue;
+      const int f0 = (tile_id / node_tiles) * TF, n0 = (tile_id % node_tiles) * TN;
+      for (int base = 0; base < TF * TN; base += kFixThreads / 4) {
+        const int o = base + (tid >> 2);
+        const int f = f0 + o / TN, node = n0 + o % TN;
+        fix_one_output(p, sh_s, sc_s, f, node, f < p.n && node < p.H, c, quads);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        p.scr_count[tile_id] = 0;
+        if (p.scr_stats) atomicAdd(p.scr_stats + 1, static_cast<unsigned long long>(TF * TN));
+      }
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0 && p.scr_stats) atomicAdd(p.scr_stats + 1, static_cast<unsigned long long>(total));
+  // (glist_count is zeroed by the next launch's pre-pass, stream-ordered before its matrix kernel)
 }
 
 template <int BK, int WFR>
@@ -1199,12 +1247,15 @@ void launch_l0(const L0Params &p, hipStream_t s) {
     const char *e = std::getenv("FDNN_L0_SPLIT_MIN");
     return e ? std::atoi(e) : 640;
   }();
-  const bool can_split = !p.fma && !no_split && !no_screen && (p.kernel == 0 || p.kernel == 4) && !p.tap_lin && p.xd && p.xstat && p.wd && p.wstat && p.luthalf &&
+  const bool can_split = !p.fma && !no_split && !no_screen && (p.kernel == 0 || p.kernel == 4) && !p.tap_lin && p.xd && p.xstat && p.wd && p.wstat && p.luthalf && p.glist && p.glist_count &&
                          p.scr_count && p.scr_list && l0_split_ok(p.D, p.H);
   if (can_split && (p.kernel == 4 || p.n >= split_min)) {
     launch_l0_split(p, s);
     const int node_tiles = p.h_ld / 128, frame_tiles = (p.n_rows + 127) / 128;
-    hipLaunchKernelGGL(l0_fix_kernel, dim3(node_tiles * frame_tiles), dim3(kFixThreads), 2 * sizeof(float) * p.D, s, p, 128);
+    // enough workgroups for 1.5 % flagged in one pass each (0.35 % on the bench batch); more is walked in further passes
+    const long expect = static_cast<long>(p.n_rows) * p.H * 3 / 200 / (kFixThreads / 4) + 8;
+    const int grid = static_cast<int>(std::min<long>(expect, 4096));
+    hipLaunchKernelGGL(l0_fix_list_kernel, dim3(grid), dim3(kFixThreads), 2 * sizeof(float) * p.D, s, p, node_tiles * frame_tiles);
     return;
   }
   if (can_screen && (p.kernel == 3 || (screened_us < (can_chain ? chain_us : tile64_us) && screened_us < tile64_us))) {

@@ -40,6 +40,7 @@
 // Measured on the 10 000-frame bench batch: see DESIGN.md section 5.
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <type_traits>
 #include <vector>
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256) void l0_digits_kernel(L0Params p, int KC, int 
   float *xs = dig_smem;                      // [8][D + 1]
   float *cf_s = dig_smem + kDigFrames * ld;  // [8]
   const int tid = threadIdx.x, f0 = blockIdx.x * kDigFrames;
+  if (blockIdx.x == 0 && tid < 2) p.glist_count[tid] = 0u;  // this launch's list of flagged outputs starts empty
   const int quads = D >> 2;
   for (int i = tid; i < kDigFrames * quads; i += 256) {
     const int row = i / quads, q = i - row * quads, f = f0 + row;
@@ -175,17 +177,27 @@ __global__ __launch_bounds__(256) void l0_digits_kernel(L0Params p, int KC, int 
 // Staging: per chunk 24 lane-linear 1-KiB LDS-DMA pieces (3 planes x 4 row blocks, both operands), three per wave,
 // 3-stage ring, one barrier per chunk -- placed between the chunk's two MFMA groups, so that the matrix pipe has work
 // while the waves meet, issue the next pieces and fetch the next fragments.
-constexpr int kSTF = 128, kSTN = 128, kSStage = 24 * 1024, kSStages = 3;
-constexpr int kSRing = kSStage * kSStages;
-constexpr int kSHalfOff = kSRing;                    // half-step table: u32 [kLut2Size] (+ pad), 11 KiB
-constexpr int kSStatOff = kSRing + 11 * 1024;        // three 1-KiB slots: r_f, ||x||_2, a_f of the tile's 128 frames (512 bytes each + the DMA piece's zero tail)
-constexpr int kSLds = kSStatOff + 3 * 1024;
-constexpr int kSTS = kSTN + 16;                      // byte tile row stride
-static_assert(kSTF * kSTS + 16 + 2 * kL0ScreenCap <= kSRing, "epilogue tile and flag list must fit in the dead ring");
+constexpr int kSTF = 128, kSStages = 3;
+template <int WN>  // node waves: 2 = 128-node tiles, 512 threads, one workgroup per CU; 1 = 64-node tiles, 256 threads, two per CU
+struct SplitCfg {
+  static constexpr int TN = 64 * WN, NW = 4 * WN, THREADS = 64 * NW;
+  static constexpr int PIECES = 12 + 6 * WN;           // 1-KiB pieces per stage: 3 planes x 4 frame blocks + 3 planes x 2 WN node blocks
+  static constexpr int STAGE = PIECES * 1024;
+  static constexpr int RING = STAGE * kSStages;
+  static constexpr int HALF_OFF = RING;                // half-step table: u32 [kLut2Size] (+ pad), 11 KiB
+  static constexpr int STAT_OFF = RING + 11 * 1024;    // three 1-KiB slots: r_f, ||x||_2, a_f of the tile's 128 frames (512 bytes each + the DMA piece's zero tail)
+  static constexpr int LDS = STAT_OFF + 3 * 1024;
+  static constexpr int TS = TN + 16;                   // byte tile row stride
+  static constexpr int PPW = (PIECES + NW - 1) / NW;   // pieces per wave and stage, at most
+  static_assert(kSTF * TS + 16 + 2 * kL0ScreenCap <= RING, "epilogue tile and flag list must fit in the dead ring");
+};
 static_assert(4 * kLut2Size <= 11 * 1024, "half-step table area");
 
-__global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, int CPC) {  // CPC: chunks per chain (even)
+template <int WN>
+__global__ __launch_bounds__(256 * WN, 3 - WN) void l0_split_kernel(L0Params p, int KC, int CPC) {  // CPC: chunks per chain (even)
 #if defined(__HIP_DEVICE_COMPILE__)
+  using Cfg = SplitCfg<WN>;
+  constexpr int kSTN = Cfg::TN, kSStage = Cfg::STAGE, kSTS = Cfg::TS, kSHalfOff = Cfg::HALF_OFF, kSStatOff = Cfg::STAT_OFF, NW = Cfg::NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,14 +219,17 @@ __global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, in
   {  // half-step table and this tile's frame constants into the aux area (LDS-DMA, ahead of the ring): 11 + 3 pieces
     const __amdgpu_buffer_rsrc_t rsrc_half =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(p.luthalf), 0, (4 * kLut2Size + 15) & ~15, 0x00020000);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_half, FDNN_LDS_PTR(smem + kSHalfOff + wave * 1024), 16, lane * 16, wave * 1024, 0, 0);
-    if (wave < 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_half, FDNN_LDS_PTR(smem + kSHalfOff + (8 + wave) * 1024), 16, lane * 16, (8 + wave) * 1024, 0, 0);
-    if (wave >= 3 && wave < 6) {  // 128 floats = 512 bytes per constant: lanes 0..31 carry them
-      const int q = wave - 3;
-      const __amdgpu_buffer_rsrc_t rsrc_st =
-          __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.xstat + static_cast<size_t>(q) * p.n_ld + f0), 0, kSTF * 4, 0x00020000);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_st, FDNN_LDS_PTR(smem + kSStatOff + q * 1024), 16, lane * 16, 0, 0, 0);
-      // (lanes 32..63 read past num_records: zeros into the slot's own tail)
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      if (i % NW != wave) continue;
+      if (i < 11) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_half, FDNN_LDS_PTR(smem + kSHalfOff + i * 1024), 16, lane * 16, i * 1024, 0, 0);
+      } else {  // 128 floats = 512 bytes per constant: lanes 0..31 carry them, lanes 32..63 read past num_records: zeros into the slot's own tail
+        const int q = i - 11;
+        const __amdgpu_buffer_rsrc_t rsrc_st =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.xstat + static_cast<size_t>(q) * p.n_ld + f0), 0, kSTF * 4, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_st, FDNN_LDS_PTR(smem + kSStatOff + q * 1024), 16, lane * 16, 0, 0, 0);
+      }
     }
   }
   const __amdgpu_buffer_rsrc_t rsrc_x =
@@ -222,16 +237,44 @@ __global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, in
   const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<int8_t *>(p.wd), 0, static_cast<unsigned>(KC) * 3u * static_cast<unsigned>(wblocks) * 1024u, 0x00020000);
   const int voff = lane * 16;
-  auto stage = [&](int kc, int buf) {
+  // my pieces of a stage: piece wave + NW t.  X pieces 0..11 = plane i / 4, frame block i % 4; W pieces 12.. = plane j / (2 WN),
+  // node block j % (2 WN).  (WN = 1: 18 pieces over 4 waves -- waves 0, 1 carry five, waves 2, 3 four.)
+  const int my_pieces = (Cfg::PIECES - wave + NW - 1) / NW;
+  auto stage_piece = [&](int kc, int buf, int t) {
     char *base = smem + buf * kSStage;
+    const int i = wave + NW * t;
+    if (i >= Cfg::PIECES) return;
+    if (i < 12) {
+      const int pl = i >> 2, q = i & 3;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, FDNN_LDS_PTR(base + i * 1024), 16, voff, ((kc * 3 + pl) * xblocks + (f0 >> 5) + q) * 1024, 0, 0);
+    } else {
+      const int j = i - 12, pl = j / (2 * WN), q = j % (2 * WN);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, FDNN_LDS_PTR(base + i * 1024), 16, voff, ((kc * 3 + pl) * wblocks + (n0 >> 5) + q) * 1024, 0, 0);
+    }
+  };
+  auto stage = [&](int kc, int buf) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      const int i = wave + 8 * t;  // piece: operand i / 12, plane (i % 12) / 4, row block i % 4
-      const int pl = (i % 12) >> 2, q = i & 3;
-      if (i < 12)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, FDNN_LDS_PTR(base + i * 1024), 16, voff, ((kc * 3 + pl) * xblocks + (f0 >> 5) + q) * 1024, 0, 0);
+    for (int t = 0; t < Cfg::PPW; ++t) stage_piece(kc, buf, t);
+  };
+  // wait until at most `stages` of my stages are still in flight
+  auto wait_stages = [&](int stages) {
+    if (stages == 0) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    } else if (Cfg::PIECES % NW == 0) {
+      if (stages == 1)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Cfg::PPW) : "memory");
       else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, FDNN_LDS_PTR(base + i * 1024), 16, voff, ((kc * 3 + pl) * wblocks + (n0 >> 5) + q) * 1024, 0, 0);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * Cfg::PPW) : "memory");
+    } else if (my_pieces == Cfg::PPW) {
+      if (stages == 1)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Cfg::PPW) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * Cfg::PPW) : "memory");
+    } else {
+      if (stages == 1)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(Cfg::PPW - 1) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (Cfg::PPW - 1)) : "memory");
     }
   };
   stage(0, 0);
@@ -259,14 +302,15 @@ __global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, in
     }
   };
   v4i xa[2][3], wb[2][3][2];  // fragment sets, double buffered over the chunks
-  auto load_frags = [&](int buf, int set) {  // (set is a literal at every call site: the lambdas are inlined)
+  auto load_plane = [&](int buf, int set, int pl) {  // (set, pl are literals at every call site: the lambdas are inlined)
     const char *sb = smem + buf * kSStage;
+    xa[set][pl] = *reinterpret_cast<const v4i *>(sb + (pl * 4 + wf) * 1024 + lane * 16);
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-      xa[set][pl] = *reinterpret_cast<const v4i *>(sb + (pl * 4 + wf) * 1024 + lane * 16);
+    for (int s = 0; s < 2; ++s) wb[set][pl][s] = *reinterpret_cast<const v4i *>(sb + 12288 + (pl * 2 * WN + wn * 2 + s) * 1024 + lane * 16);
+  };
+  auto load_frags = [&](int buf, int set) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) wb[set][pl][s] = *reinterpret_cast<const v4i *>(sb + 12288 + (pl * 4 + wn * 2 + s) * 1024 + lane * 16);
-    }
+    for (int pl = 0; pl < 3; ++pl) load_plane(buf, set, pl);
   };
   // The samples of node half ss (its P0 is complete: one MFMA group ago) go into the issue slots between the MFMAs of
   // half s -- fenced, or the scheduler runs the 16 vector instructions before or after the MFMAs instead of beside them.
@@ -279,37 +323,47 @@ __global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, in
     for (int r = r0; r < r1; ++r) asm volatile("v_sad_u32 %0, %1, 2.0, %0" : "+v"(A[ss][r]) : "v"(P0[ss][r]));
   };
 #define FDNN_L0S_FENCE __builtin_amdgcn_sched_barrier(0)
-  auto mfma_group = [&](int set, int s, int ss, bool on) {
+  // (x0 .. x4: what else goes between the MFMAs -- the refill pieces and the next chunk's fragment reads in the second
+  // group of a chunk: an LDS-DMA piece costs its wave 60-180 cycles of issue, which the matrix pipe spends on the other
+  // wave's MFMA instead of idling behind the barrier)
+  auto mfma_group = [&](int set, int s, int ss, bool on, auto x0, auto x1, auto x2, auto x3, auto x4) {
     FDNN_L0S_FENCE;
     P0[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][0], wb[set][0][s], P0[s], 0, 0, 0);
     if (FDNN_L0S_DEBUG & 2) {
       sample_part(ss, 0, 16, on);
+      x0(); x1(); x2(); x3(); x4();
       return;
     }
     FDNN_L0S_FENCE;
     sample_part(ss, 0, 3, on);
+    x0();
     FDNN_L0S_FENCE;
     P1[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][0], wb[set][1][s], P1[s], 0, 0, 0);
     FDNN_L0S_FENCE;
     sample_part(ss, 3, 6, on);
+    x1();
     FDNN_L0S_FENCE;
     P2[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][0], wb[set][2][s], P2[s], 0, 0, 0);
     FDNN_L0S_FENCE;
     sample_part(ss, 6, 9, on);
+    x2();
     FDNN_L0S_FENCE;
     P1[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][1], wb[set][0][s], P1[s], 0, 0, 0);
     FDNN_L0S_FENCE;
     sample_part(ss, 9, 12, on);
+    x3();
     FDNN_L0S_FENCE;
     P2[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][1], wb[set][1][s], P2[s], 0, 0, 0);
     FDNN_L0S_FENCE;
     sample_part(ss, 12, 16, on);
+    x4();
     FDNN_L0S_FENCE;
     P2[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(xa[set][2], wb[set][0][s], P2[s], 0, 0, 0);
     FDNN_L0S_FENCE;
   };
+  auto nothing = [] {};
 
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // chunk 0 (and the aux pieces before it) landed; chunks 1, 2 may be in flight
+  wait_stages(2);  // chunk 0 (and the aux pieces before it) landed; chunks 1, 2 may be in flight
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   load_frags(0, 0);
@@ -321,19 +375,22 @@ __global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, in
     constexpr int set = decltype(set_c)::value;  // (compile time: the fragment sets are registers)
     constexpr bool first = decltype(first_c)::value;
     if (chain_start) chain_end(0);  // (wave-uniform, three times per tile)
-    mfma_group(set, 0, 1, !first);
-    if (kc + 1 < KC) {
-      if (kc + 2 < KC)
-        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");  // my three pieces of chunk kc + 2 may still be in flight
-      else
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // chunk kc + 1 landed for everyone, everyone has read chunk kc (its fragments are in registers)
+    mfma_group(set, 0, 1, !first, nothing, nothing, nothing, nothing, nothing);
+    const bool more = kc + 1 < KC, refill = kc + 3 < KC && !(FDNN_L0S_DEBUG & 8);
+    if (more) {
+      wait_stages(kc + 2 < KC ? 1 : 0);  // my pieces of chunk kc + 2 may still be in flight
+      if (!(FDNN_L0S_DEBUG & 16)) __builtin_amdgcn_s_barrier();  // chunk kc + 1 landed for everyone, everyone has read chunk kc (its fragments are in registers)
       asm volatile("" ::: "memory");
-      if (kc + 3 < KC && !(FDNN_L0S_DEBUG & 8)) stage(kc + 3, kc % 3);  // into the buffer chunk kc has just left
-      load_frags((kc + 1) % 3, set ^ 1);
     }
     if (chain_start) chain_end(1);
-    mfma_group(set, 1, 0, true);
+    // second group: the refill of the buffer chunk kc has just left (chunk kc + 3) and the fragments of chunk kc + 1 go
+    // out between its MFMAs
+    const int nb = (kc + 1) % 3;
+    mfma_group(
+        set, 1, 0, true, [&] { if (more && !(FDNN_L0S_DEBUG & 32)) load_plane(nb, set ^ 1, 0); if (refill) stage_piece(kc + 3, kc % 3, 0); },
+        [&] { if (more && !(FDNN_L0S_DEBUG & 32)) load_plane(nb, set ^ 1, 1); if (refill) stage_piece(kc + 3, kc % 3, 1); },
+        [&] { if (more && !(FDNN_L0S_DEBUG & 32)) load_plane(nb, set ^ 1, 2); if (refill) stage_piece(kc + 3, kc % 3, 2); },
+        [&] { if (refill && Cfg::PPW > 3) stage_piece(kc + 3, kc % 3, 3); }, [&] { if (refill && Cfg::PPW > 4) stage_piece(kc + 3, kc % 3, 4); });
   };
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
@@ -447,19 +504,35 @@ __global__ __launch_bounds__(512, 1) void l0_split_kernel(L0Params p, int KC, in
     }
   }
 #pragma unroll
-  for (int q = 0; q < kSTF * 8 / 512; ++q) {  // the byte tile leaves as 128-byte row segments
-    const int item = tid + q * 512, row = item >> 3, c16 = (item & 7) * 16;
+  for (int q = 0; q < kSTF * (kSTN / 16) / Cfg::THREADS; ++q) {  // the byte tile leaves as whole row segments
+    const int item = tid + q * Cfg::THREADS, row = item / (kSTN / 16), c16 = (item % (kSTN / 16)) * 16;
     const int f = f0 + row;
     if (f < p.n_rows && n0 + c16 < p.H)  // H is a multiple of 16
       *reinterpret_cast<uint4 *>(p.act_out + static_cast<size_t>(f) * p.act_ld + n0 + c16) = *reinterpret_cast<const uint4 *>(tile + row * kSTS + c16);
   }
   __syncthreads();
-  {
-    const int tile_id = by * node_tiles + bx;
+  {  // the tile's entries join the launch's list: one global atomic per tile reserves the room
     const uint32_t cnt = *scr_n;
-    if (tid == 0) p.scr_count[tile_id] = cnt;  // > kL0ScreenCap: the fix kernel recomputes the whole tile
-    const uint32_t listed = min(cnt, static_cast<uint32_t>(kL0ScreenCap));
-    for (uint32_t i = tid; i < listed; i += 512) p.scr_list[static_cast<size_t>(tile_id) * kL0ScreenCap + i] = scr_l[i];
+    uint32_t *gbase_s = scr_n + 1;
+    if (tid == 0) {
+      uint32_t gb = 0xffffffffu;
+      if (cnt != 0 && cnt <= static_cast<uint32_t>(kL0ScreenCap)) {
+        gb = atomicAdd(p.glist_count, cnt);
+        if (gb + cnt > static_cast<uint32_t>(p.glist_cap)) gb = 0xffffffffu;  // (the list is full: the fix kernel clamps its walk to the capacity)
+      }
+      if (cnt != 0 && gb == 0xffffffffu) {  // too many for either list: the fix kernel recomputes the whole tile
+        p.scr_count[by * (p.h_ld / 128) + (n0 >> 7)] = cnt;  // (the whole-tile path works on 128 x 128 tiles)
+        atomicAdd(p.glist_count + 1, 1u);
+      }
+      *gbase_s = gb;
+    }
+    __syncthreads();
+    const uint32_t gb = *gbase_s;
+    if (gb != 0xffffffffu)
+      for (uint32_t i = tid; i < cnt; i += Cfg::THREADS) {
+        const uint32_t e = scr_l[i];
+        p.glist[gb + i] = make_uint2(static_cast<uint32_t>(f0) + e / kSTN, static_cast<uint32_t>(n0) + e % kSTN);
+      }
   }
 #ifdef FDNN_L0S_CLK
   L0S_TS(5);
@@ -552,14 +625,22 @@ void launch_l0_split(const L0Params &p, hipStream_t s) {
   (void)hipGetDevice(&dev);
   const unsigned long long dev_bit = 1ull << (dev & 63);
   const int dig_lds = (kDigFrames * (p.D + 1) + kDigFrames) * 4;
+  static const int wn_cfg = [] {
+    const char *e = std::getenv("FDNN_L0S_WN");
+    return e && std::atoi(e) == 1 ? 1 : 2;  // (64-node tiles, two workgroups per CU: measured equal, 99.2 vs 97.7 us)
+  }();
   if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {
-    hipFuncSetAttribute(reinterpret_cast<const void *>(l0_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kSLds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(l0_split_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, SplitCfg<1>::LDS);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(l0_split_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, SplitCfg<2>::LDS);
     attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
-  const int frame_tiles = (p.n_rows + kSTF - 1) / kSTF, node_tiles = p.h_ld / kSTN;
+  const int frame_tiles = (p.n_rows + kSTF - 1) / kSTF;
   const int dig_rows = frame_tiles * kSTF;  // every row a matrix tile will read (<= n_ld)
   hipLaunchKernelGGL(l0_digits_kernel, dim3(dig_rows / kDigFrames), dim3(256), dig_lds, s, p, KC, J, JP);
-  hipLaunchKernelGGL(l0_split_kernel, dim3(static_cast<unsigned>(node_tiles) * ((frame_tiles + 7) / 8) * 8), dim3(512), kSLds, s, p, KC, JP / 32);
+  if (wn_cfg == 2)
+    hipLaunchKernelGGL(l0_split_kernel<2>, dim3(static_cast<unsigned>(p.h_ld / 128) * ((frame_tiles + 7) / 8) * 8), dim3(512), SplitCfg<2>::LDS, s, p, KC, JP / 32);
+  else
+    hipLaunchKernelGGL(l0_split_kernel<1>, dim3(static_cast<unsigned>(p.h_ld / 64) * ((frame_tiles + 7) / 8) * 8), dim3(256), SplitCfg<1>::LDS, s, p, KC, JP / 32);
 }
 
 }  // namespace fdnn

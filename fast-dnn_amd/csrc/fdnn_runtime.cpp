@@ -147,6 +147,8 @@ void destroy_ctx(fdnn_ctx *c) {
   hipFree(c->d_scr_count);
   hipFree(c->d_xd);
   hipFree(c->d_xstat);
+  hipFree(c->d_glist);
+  hipFree(c->d_glist_count);
   hipFree(c->d_scr_list);
   hipFree(c->d_act[0]);
   hipFree(c->d_act[1]);
@@ -197,6 +199,10 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
   if (m->d_w0d) {  // int8 screening: the frames' digit planes and row constants
     alloc(reinterpret_cast<void **>(&c->d_xd), fdnn::l0_split_plane_bytes(h.in_dim, c->xt_ld));
     alloc(reinterpret_cast<void **>(&c->d_xstat), sizeof(float) * 3 * size_t(c->xt_ld));
+    c->glist_cap = int(std::min<size_t>(size_t(c->xt_ld) * size_t(m->l0_h_ld) / 16, size_t(1) << 26));  // 6 % of the outputs
+    alloc(reinterpret_cast<void **>(&c->d_glist), sizeof(uint2) * size_t(c->glist_cap));
+    alloc(reinterpret_cast<void **>(&c->d_glist_count), sizeof(uint32_t) * 2);
+    if (e == hipSuccess) e = hipMemset(c->d_glist_count, 0, sizeof(uint32_t) * 2);
   }
   if (fdnn::l0_chain_node_tile() == 128)  // the 64-node tile keeps its partial sums in registers
     alloc(reinterpret_cast<void **>(&c->d_l0park), sizeof(float) * size_t(c->xt_ld) * m->l0_h_ld);
@@ -334,6 +340,9 @@ void run_layer0(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) 
   l0.wd = m->d_w0d;
   l0.wstat = m->d_w0stat;
   l0.luthalf = m->d_lutpair;
+  l0.glist = c->d_glist;
+  l0.glist_count = c->d_glist_count;
+  l0.glist_cap = c->glist_cap;
   l0.j_pad = m->l0_j_pad;
   l0.jc = m->l0_jc;
   l0.n_ld = c->xt_ld;
