@@ -82,27 +82,47 @@ __global__ __launch_bounds__(256) void l0_digits_kernel(L0Params p, int KC, int 
   const int tid = threadIdx.x, f0 = blockIdx.x * kDigFrames;
   if (blockIdx.x == 0 && tid < 2) p.glist_count[tid] = 0u;  // this launch's list of flagged outputs starts empty
   const int quads = D >> 2;
-  for (int i = tid; i < kDigFrames * quads; i += 256) {
-    const int row = i / quads, q = i - row * quads, f = f0 + row;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f < p.n) {
-      const float4 raw = *reinterpret_cast<const float4 *>(p.x + static_cast<size_t>(f) * D + 4 * q);
-      const float4 sh = *reinterpret_cast<const float4 *>(p.shift + 4 * q), sc = *reinterpret_cast<const float4 *>(p.scale + 4 * q);
-      v.x = (raw.x + sh.x) * sc.x;
-      v.y = (raw.y + sh.y) * sc.y;
-      v.z = (raw.z + sh.z) * sc.z;
-      v.w = (raw.w + sh.w) * sc.w;
+  {
+    // all of a thread's loads first (at most four 16-byte pieces of the rows, D <= 496), then the arithmetic: with a load,
+    // its wait and its LDS stores per iteration the loop was four HBM round trips long (11 us per workgroup)
+    float4 raw[4], sh[4], sc[4];
+    int rowq[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i = tid + it * 256;
+      const int row = i / quads, q = i - row * quads, f = f0 + row;
+      const bool in = i < kDigFrames * quads;
+      rowq[it] = in ? row * ld + 4 * q : -1;
+      raw[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      sh[it] = raw[it];
+      sc[it] = raw[it];
+      if (in && f < p.n) {
+        raw[it] = *reinterpret_cast<const float4 *>(p.x + static_cast<size_t>(f) * D + 4 * q);
+        sh[it] = *reinterpret_cast<const float4 *>(p.shift + 4 * q);
+        sc[it] = *reinterpret_cast<const float4 *>(p.scale + 4 * q);
+      }
     }
-    float *dst = xs + row * ld + 4 * q;
-    dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      if (rowq[it] < 0) continue;
+      float *dst = xs + rowq[it];  // rows past the batch: zeros ((0 + 0) * 0)
+      dst[0] = (raw[it].x + sh[it].x) * sc[it].x;  // ApplyShiftAndScale: add, then multiply (dnn.cc:184-187)
+      dst[1] = (raw[it].y + sh[it].y) * sc[it].y;
+      dst[2] = (raw[it].z + sh[it].z) * sc[it].z;
+      dst[3] = (raw[it].w + sh[it].w) * sc[it].w;
+    }
   }
   __syncthreads();
   {
     const int row = tid >> 5, sub = tid & 31;
     float mx = 0.0f, s2 = 0.0f, s1 = 0.0f;
     int bad = 0;
-    for (int k = sub; k < D; k += 32) {
-      const float v = xs[row * ld + k], a = fabsf(v);
+    float vals[16];  // (D <= 496: at most 16 per lane; all LDS reads go out before the first is used)
+#pragma unroll
+    for (int it = 0; it < 16; ++it) vals[it] = sub + 32 * it < D ? xs[row * ld + sub + 32 * it] : 0.0f;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const float v = vals[it], a = fabsf(v);
       bad |= !(a < 3.0e38f);  // inf or NaN
       mx = fmaxf(mx, a);
       s2 = fmaf(v, v, s2);
@@ -443,23 +463,36 @@ __global__ __launch_bounds__(256 * WN, 3 - WN) void l0_split_kernel(L0Params p, 
     valid |= (row_in && node_in[0] ? 1u : 0u) << r;
     valid |= (row_in && node_in[1] ? 1u : 0u) << (16 + r);
   }
-  uint32_t scr_mask = 0;
+  // pass 1: t = 100 lin~ and sigma for all 32 outputs, and their table entries requested -- all the gathers are in flight
+  // before the first is needed (one gather and its wait per output was 32 exposed LDS round trips per wave)
+  float tt[2][16], sg[2][16];
+  uint32_t ent[2][16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int row = wf * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-    const float rf = rf_s[row], xn = xn_s[row], af = af_s[row];
+    const float rf = rf_s[wf * 32 + 8 * (r >> 2) + 4 * h + (r & 3)];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       // V = 2^-8 (P1' + 2^-8 P2), P1' = 256 P0 + P1 in int32; sig = 100 * 2^24 / (c_f c_n);  t ~ 100 lin (dnn.h:37)
       const float v = fmaf(static_cast<float>(P2[s][r]), 0.00390625f, static_cast<float>(P1[s][r]));
-      const float sig = rf * rn100[s];
-      const float t = fmaf(v, sig, bias100[s]);
+      sg[s][r] = rf * rn100[s];
+      tt[s][r] = fmaf(v, sg[s][r], bias100[s]);
       // QuantizedSigmoid::get through the half-step table (fdnn_model.cpp): index trunc(2 t), clamped; the entry carries the
       // table byte and, in its upper half, a gate: 0.25f where the byte on the other side of the nearest half-integer is
       // the same, else 0
-      const int u = max(-kLut2Half, min(kLut2Half, static_cast<int>(t + t)));  // (v_cvt_i32_f32 truncates, saturates, NaN -> 0)
-      const uint32_t ent = *reinterpret_cast<const uint32_t *>(half_b + 4 * u);
-      tile[row * kSTS + wn * 64 + s * 32 + l32] = static_cast<uint8_t>(ent);
+      const int u = max(-kLut2Half, min(kLut2Half, static_cast<int>(tt[s][r] + tt[s][r])));  // (v_cvt_i32_f32 truncates, saturates, NaN -> 0)
+      ent[s][r] = *reinterpret_cast<const uint32_t *>(half_b + 4 * u);
+    }
+  }
+  // pass 2: the table bytes into the tile, and the screening
+  uint32_t scr_mask = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wf * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+    const float xn = xn_s[row], af = af_s[row];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float t = tt[s][r], sig = sg[s][r];
+      tile[row * kSTS + wn * 64 + s * 32 + l32] = static_cast<uint8_t>(ent[s][r]);
       if (!(FDNN_L0S_DEBUG & 4)) {
         const float e = __builtin_amdgcn_fractf(t) - 0.5f;  // against the half-integer above floor(t): the nearest one
         const float Dd = fmaf(fabsf(t), 12.0f * kU, fmaf(sig, fmaf(kA, static_cast<float>(A[s][r]), af + bn2[s]), fmaf(kSw2[s], xn, eb2[s]))) + 1e-30f;
@@ -467,10 +500,10 @@ __global__ __launch_bounds__(256 * WN, 3 - WN) void l0_split_kernel(L0Params p, 
         // reach), AND not both clamped to the same end of the table (|t| - Dd >= 641)  ==  max(|e|, gate, |t| - 641) <= Dd,
         // written so that a NaN flags.  x86 float -> int turns NaN and |t| >= 2^31 into INT_MIN (entry 0 after the clamp,
         // lut_index): anything near that takes the exact path as well.
-        const float gate = __builtin_bit_cast(float, ent & 0xffff0000u);
+        const float gate = __builtin_bit_cast(float, ent[s][r] & 0xffff0000u);
         const float m = fmaxf(fmaxf(fabsf(e), gate), fabsf(t) - 641.0f);
         const bool flag = !(m > Dd) | !(fabsf(t) < 1.0e9f);
-        if (__builtin_amdgcn_ballot_w64(flag)) scr_mask |= flag ? (1u << (16 * s + r)) : 0u;  // (rare: one output in 300)
+        scr_mask |= flag ? (1u << (16 * s + r)) : 0u;
       }
     }
   }

@@ -141,18 +141,19 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
   c->n = n;
   c->last = -1;
   const bool small = n <= kSmallBatch;
-  // Large batches, two ways (FDNN_SERVER_OVERLAP=0|1): "overlap" = all-VALU chain layer 0 with the previous batch's
-  // soft-max scale as a background kernel underneath it; "serial" = the screened matrix-pipe layer 0 (65 us shorter) and
-  // the ordinary full-grid scale kernel in line.  The matrix kernel admits nothing beside it.
+  // Large batches whose output layer cannot scale its own soft-max (odd widths, FDNN_FUSE_NORM=0; dense and batched-lazy
+  // batches of the usual shapes can, and have no scale pass at all): the scale pass runs in line behind the output GEMM.
+  // FDNN_SERVER_OVERLAP=1 restores round 2's arrangement -- the pass as a background kernel on the tail stream under
+  // the next batch's layer 0, which must then be the all-VALU chain kernel (the matrix-pipe kernels fill the register
+  // file) -- worth it while layer 0 took 270 us; with the int8 screening (140 us) the chain kernel's 325 us lose.
   static const bool overlap = [] {
     const char *e = std::getenv("FDNN_SERVER_OVERLAP");
-    return e ? std::atoi(e) != 0 : true;
+    return e ? std::atoi(e) != 0 : false;
   }();
-  // (a dense large batch scales its soft-max inside the output kernel: no pass to overlap, layer 0 takes the faster
-  // screened path; the chain kernel + background scale pass remain for lazy batches)
-  const int chunk_n = small ? n : fdnn::frame_chunks(n).front().second;
-  const bool fused = !small && fdnn::output_will_fuse(c, chunk_n, d_masks);
-  c->l0_chain_only = !small && overlap && !fused;  // see fdnn_ctx: the overlapped scale pass needs room beside layer 0
+  const std::vector<std::pair<int, int>> chunks = small ? std::vector<std::pair<int, int>>{} : fdnn::frame_chunks(n);
+  bool all_fused = !small;
+  for (const auto &ch : chunks) all_fused = all_fused && fdnn::output_will_fuse(c, ch.second, d_masks);  // (a short tail chunk may take the unfused kernels)
+  c->l0_chain_only = !small && overlap && !all_fused;  // see fdnn_ctx: an overlapped scale pass needs room beside layer 0
   hipStream_t cs = small ? sl.stream : s->s_main;
   if (after) HIP_TRY(hipStreamWaitEvent(cs, after, 0));
   HIP_TRY(fdnn::ctx_enter(c, cs));
@@ -168,7 +169,7 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
     // read them: it waits for `tail_done` there.
     const size_t D = size_t(s->m->hm.hdr.in_dim), O = size_t(s->m->hm.hdr.out_dim);
     bool first = true;
-    for (const auto &ch : fdnn::frame_chunks(n)) {
+    for (const auto &ch : chunks) {
       c->n = ch.second;
       rc = fdnn::run_hidden(c, d_x + size_t(ch.first) * D, cs, nullptr);
       if (rc) break;

@@ -415,3 +415,67 @@ def test_int8_screening_with_hostile_rows(net_model_path):
     chain, _ = dnn.layer0(x)
     assert np.array_equal(chain, got)
     dnn.delete()
+
+
+def test_fused_softmax_under_many_streams_and_two_models(net_model_path, tmp_models):
+    """The fused soft-max's workgroups wait for their frame tile's other node tiles -- safe while one such kernel is being
+    dispatched, a latency cliff (bounded waits of tens of milliseconds, then the clean-up kernel) when nine partially
+    dispatched frame tiles from different launches fill the chip.  The library chains the fused launches of a device
+    (fdnn_runtime.cpp: FuseChain), whatever stream, context or model they come from.  Here: 8 caller threads, each with
+    its own stream, fdnn_calculate_device at 10 000 frames on the full net, and a ninth thread scoring a SECOND model on
+    the same device, 50 rounds -- every result bit-identical to the single-stream one, no tile ever left to the
+    clean-up kernel (fdnn_model_fuse_giveups), no call far beyond the median.  (SoftMax::apply, dnn.cc:534-544;
+    concurrency model: MultiThreadedStressTest.java:48-61.)"""
+    import threading
+    import time
+
+    import torch
+
+    n, T, rounds = 10000, 8, 50
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    p2 = os.path.join(tmp_models, "second_fused.bin")
+    F.write_model_bin(p2, F.synth_net([432, 512, 512, 512, 2048], seed=77))
+    dnn2 = api.QuantizedDnn.loadFromFile(p2)
+    O, O2 = dnn.outputDimension(), dnn2.outputDimension()
+    x = torch.from_numpy(F.synth_features(n, 432, seed=41)).cuda()
+    ref = torch.empty((n, O), dtype=torch.float32, device="cuda")
+    ref2 = torch.empty((n, O2), dtype=torch.float32, device="cuda")
+    dnn.calculate_device(x.data_ptr(), n, ref.data_ptr(), 0)
+    dnn2.calculate_device(x.data_ptr(), n, ref2.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert abs(float(ref[:64].sum(1).mean()) - 1.0) < 1e-3
+    outs = [torch.empty((n, O), dtype=torch.float32, device="cuda") for _ in range(T)]
+    out2 = torch.empty((n, O2), dtype=torch.float32, device="cuda")
+    streams = [torch.cuda.Stream() for _ in range(T + 1)]
+    times = [[] for _ in range(T + 1)]
+    bad = []
+    go = threading.Barrier(T + 1)
+
+    def caller(t):
+        s = streams[t]
+        go.wait()
+        for _ in range(rounds):
+            t0 = time.perf_counter()
+            if t < T:
+                dnn.calculate_device(x.data_ptr(), n, outs[t].data_ptr(), s.cuda_stream)
+            else:
+                dnn2.calculate_device(x.data_ptr(), n, out2.data_ptr(), s.cuda_stream)
+            s.synchronize()
+            times[t].append(time.perf_counter() - t0)
+            got, want = (outs[t], ref) if t < T else (out2, ref2)
+            if not torch.equal(got, want):
+                bad.append(t)
+
+    th = [threading.Thread(target=caller, args=(t,)) for t in range(T + 1)]
+    for h in th:
+        h.start()
+    for h in th:
+        h.join()
+    assert not bad, f"threads {sorted(set(bad))} saw results that differ from the single-stream ones"
+    if not os.environ.get("FDNN_FUSE_NORM"):
+        assert dnn.fuseGiveups() == 0 and dnn2.fuseGiveups() == 0
+    allt = sorted(v for t in range(T) for v in times[t][2:])
+    med, p99 = allt[len(allt) // 2], allt[int(len(allt) * 0.99)]
+    assert p99 < 3.0 * med + 2e-3, (med, p99)   # (nine callers share one GPU: a call takes ~9 single-stream times; no cliff)
+    dnn.delete()
+    dnn2.delete()

@@ -1,5 +1,5 @@
-"""Layer-0 time per kernel choice (0 = library's choice, 1 = chain kernel, 2 = 64 x 64-tile kernel) against the
-batch size, to calibrate launch_l0's cost model.  Run on the GPU box."""
+"""Layer-0 time per kernel choice (0 = library's choice, 1 = chain kernel, 2 = 64 x 64-tile kernel, 4 = int8 screening)
+against the batch size, to calibrate launch_l0's choice.  Run on the GPU box."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
@@ -11,10 +11,10 @@ NMAX = 10240
 big = torch.from_numpy(F.synth_features(NMAX, 432, seed=5)).cuda()
 out = torch.empty((NMAX, 8000), dtype=torch.float32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
-sizes = [int(a) for a in os.environ.get("FRAMES", "8 100 256 512 768 1000 1500 2000 2560 3000 3500 4000 4500 5000 5500 6000 6500 7000 7500 8500 9000").split()]
+sizes = [int(a) for a in os.environ.get("FRAMES", "8 100 128 200 256 384 512 640 768 1000 1280 1500 2000 2560 3000 4000 5000 6000 7500 9000 10000").split()]
 for n in sizes:
     row = {}
-    for kind in (0, 1, 2):
+    for kind in (0, 1, 2, 4):
         dnn.setInputLayerKernel(kind)
         for _ in range(30): dnn.calculate_device(big.data_ptr(), n, out.data_ptr(), s)
         torch.cuda.synchronize()
@@ -24,16 +24,4 @@ for n in sizes:
         prof = dnn.profileEnd()
         row[kind] = round(prof["l0"]["ms"] / 20 * 1e3, 1)
     dnn.setInputLayerKernel(0)
-    print(f"n={n:6d}  l0 us: auto {row[0]:7.1f}  chain {row[1]:7.1f}  tile64 {row[2]:7.1f}", flush=True)
-# wall time against kernel time around the 9000-frame outlier of batch_sweep
-for n in (8500, 9000, 9500, 10000):
-    for _ in range(50): dnn.calculate_device(big.data_ptr(), n, out.data_ptr(), s)
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(60):
-        t0 = time.perf_counter(); dnn.calculate_device(big.data_ptr(), n, out.data_ptr(), s); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-    ts.sort()
-    t0 = time.perf_counter()
-    for _ in range(100): dnn.calculate_device(big.data_ptr(), n, out.data_ptr(), s)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 100
-    print(f"n={n}: one call at a time p10 {ts[6]*1e6:.0f} p50 {ts[30]*1e6:.0f} p90 {ts[54]*1e6:.0f} us; 100 queued calls {dt*1e6:.0f} us/call", flush=True)
+    print(f"n={n:6d}  l0 us: auto {row[0]:7.1f}  chain {row[1]:7.1f}  tile64 {row[2]:7.1f}  int8 screening {row[4]:7.1f}", flush=True)
