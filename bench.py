@@ -495,6 +495,7 @@ def main() -> None:
 
     # ---- BASELINE configs[3]: the lazy contract, 40 % of the output nodes active, 3 % churn per frame
     lazy = None
+    steps_for_ratio = args.steps
     if world == 1 and not args.no_lazy:
         masks = F.generate_masks_fast(n, O, 0.40, 0.03, seed=11)
         active = float(masks.mean())
@@ -528,7 +529,33 @@ def main() -> None:
                     "byte masks (80 MB per step) are packed to bits by one HBM pass (mask_pack_kernel) and the GEMM reads one "
                     "64-bit word per frame row and 64 nodes",
         }
-        del md, masks
+        # the same contract with the masks as bits (fdnn_ctx_lazy_output_batch_bits_device): no 80 MB of mask bytes, no pack pass
+        bd = torch.from_numpy(F.pack_mask_bits(masks).view(np.int64)).to(dev)
+        ctx = dnn.getNewLazyContext(n)
+        lz = outs[0]
+
+        def lazy_bits_step():
+            ctx.calculateUntilOutputDevice(x.data_ptr(), stream.cuda_stream)
+            ctx.calculateForOutputNodesBatchBitsDevice(bd.data_ptr(), lz.data_ptr(), 0, n, stream.cuda_stream)
+
+        for _ in range(args.warmup):
+            lazy_bits_step()
+        torch.cuda.synchronize()
+        t3b = time.perf_counter()
+        for _ in range(k_lazy):
+            lazy_bits_step()
+        torch.cuda.synchronize()
+        bits_s = (time.perf_counter() - t3b) / k_lazy
+        md_ref = torch.empty_like(lz)
+        ctx.calculateForOutputNodesBatchDevice(md.data_ptr(), md_ref.data_ptr(), 0, n, stream.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(md_ref, lz), "bit-mask and byte-mask results differ"
+        ctx.delete()
+        lazy["bit_masks"] = {"frames_per_s": round(n / bits_s, 1), "ms_per_step": round(bits_s * 1e3, 4), "steps": k_lazy,
+                             "vs_dense_single_stream": round((single_elapsed / steps_for_ratio) / bits_s, 4),
+                             "note": "LazyContext on one stream: calculateUntilOutput + fdnn_ctx_lazy_output_batch_bits_device, masks as "
+                                     "uint64 [n][125] (10 MB), device resident; compared with the dense single-stream step"}
+        del md, masks, bd, md_ref
 
     # ---- small batches, device resident: one utterance (100 frames = 1 s of speech, the reference's own call shape) and
     # a decoder-sized block (8 frames) per call, calls back to back on one stream.  The regime is bound by streaming the

@@ -98,6 +98,8 @@ SIGNATURES = {
     "fdnn_debug_production_acc_out": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, _c_i8p, _c_i32p, _c_f32p]),
     "fdnn_debug_forward_taps": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_i8p, _c_f32p, _c_u8p, _c_i32p, _c_i32p, _c_f32p, _c_f32p]),
     "fdnn_debug_layer0": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_u8p, C.POINTER(C.c_ulonglong)]),
+    "fdnn_ctx_lazy_output_batch_bits": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "fdnn_ctx_lazy_output_batch_bits_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fdnn_model_fuse_giveups": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "fdnn_debug_device_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]),
     "fdnn_profile_begin": (C.c_int, [C.c_void_p]),
@@ -222,6 +224,19 @@ class LazyContext:
         return out
 
     # device-resident forms (raw device pointers, e.g. ``tensor.data_ptr()``; enqueued on ``stream``)
+    def calculateForOutputNodesBatchBits(self, bits, first: int = 0) -> np.ndarray:
+        """Batched lazy output with the masks as bits: uint64 [count][ceil(O / 64)] (formats.pack_mask_bits)."""
+        b = np.ascontiguousarray(bits, dtype=np.uint64)
+        O = self.dnn.outputDimension()
+        if b.ndim != 2 or b.shape[1] != (O + 63) // 64:
+            raise ValueError("bits must be [count][ceil(outputDimension / 64)] uint64")
+        out = np.empty((b.shape[0], O), dtype=np.float32)
+        _check(lib().fdnn_ctx_lazy_output_batch_bits(self.handle, first, b.shape[0], b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def calculateForOutputNodesBatchBitsDevice(self, d_bits: int, d_out: int, first: int, count: int, stream: int = 0) -> None:
+        _check(lib().fdnn_ctx_lazy_output_batch_bits_device(self.handle, first, count, C.c_void_p(d_bits), C.c_void_p(d_out), C.c_void_p(stream)))
+
     def calculateUntilOutputDevice(self, d_input: int, stream: int = 0) -> None:
         _check(lib().fdnn_ctx_forward_hidden_device(self.handle, C.c_void_p(d_input), C.c_void_p(stream)))
 

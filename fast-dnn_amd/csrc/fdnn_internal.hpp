@@ -132,7 +132,9 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps);
 // `tail` is given, on that stream behind an event (`gemm_done`) recorded on s, so that the
 // HBM-bound scale pass can run under the next batch's layer 0.
 int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out, hipStream_t s, const Taps *taps,
-               float *d_final = nullptr, hipStream_t tail = nullptr, hipEvent_t gemm_done = nullptr);
+               float *d_final = nullptr, hipStream_t tail = nullptr, hipEvent_t gemm_done = nullptr, const uint64_t *d_bits = nullptr);
+// (d_bits: the masks of the same frames as BITS, [count][ceil(O / 64)], bit b of word w = node 64 w + b; then d_masks may be
+// null -- large batches read the words as they are, small ones unpack them into the context's byte mask first)
 // Will run_output scale the soft-max inside the output kernel for such a call (dense, large batch)?  Then there is no
 // scale pass to hide under the next batch's layer 0.
 bool output_will_fuse(fdnn_ctx *c, int count, const int8_t *d_masks);

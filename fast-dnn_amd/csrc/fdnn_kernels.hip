@@ -203,7 +203,22 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(const int8_t *mask, uint
   }
 }
 
+// the other way (bit-mask entry points, small batches: the small-batch kernels read mask bytes): byte [f][c] = bit c & 63 of word [f][c >> 6]
+__global__ __launch_bounds__(256) void mask_unpack_kernel(const uint64_t *bits, int8_t *mask, int n, int rows, int wpr) {
+  const long long total = static_cast<long long>(n) * rows;
+  for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long long>(gridDim.x) * 256) {
+    const int f = static_cast<int>(i / rows), c = static_cast<int>(i - static_cast<long long>(f) * rows);
+    mask[i] = static_cast<int8_t>((bits[static_cast<size_t>(f) * wpr + (c >> 6)] >> (c & 63)) & 1ull);
+  }
+}
+
 }  // namespace
+
+void launch_mask_unpack(const uint64_t *bits, int8_t *mask, int n, int rows, hipStream_t s) {
+  const long long total = static_cast<long long>(n) * rows;
+  const int blocks = static_cast<int>(std::min<long long>((total + 255) / 256, 256 * 16));
+  if (blocks > 0) hipLaunchKernelGGL(mask_unpack_kernel, dim3(blocks), dim3(256), 0, s, bits, mask, n, rows, (rows + 63) / 64);
+}
 
 void launch_mask_pack(const int8_t *mask, uint64_t *bits, int n, int rows, hipStream_t s) {
   const int wpr = (rows + 63) / 64;

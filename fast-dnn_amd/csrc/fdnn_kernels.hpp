@@ -129,6 +129,7 @@ void launch_qgemm_output(const QGemmParams &p, hipStream_t s);
 // contract's byte masks (80 MB for 10 000 frames x 8000 nodes) are read once here, at HBM speed, instead of inside the
 // output GEMM's epilogue.
 void launch_mask_pack(const int8_t *mask, uint64_t *bits, int n, int rows, hipStream_t s);
+void launch_mask_unpack(const uint64_t *bits, int8_t *mask, int n, int rows, hipStream_t s);
 
 // dst[f][:] = out[f][:] / sum_t partial[t][f]   (dst == out: in place; dst may be host-mapped)
 // background: a small fixed grid walking the rows (server loop: runs under the next batch's layer 0)

@@ -394,7 +394,7 @@ static FuseChain &fuse_chain(int device) {
 }
 
 int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out, hipStream_t s, const Taps *taps,
-               float *d_final, hipStream_t tail, hipEvent_t gemm_done) {  // d_final: where the probabilities go (default: in place in d_out)
+               float *d_final, hipStream_t tail, hipEvent_t gemm_done, const uint64_t *d_bits) {  // d_final: where the probabilities go (default: in place in d_out)
   fdnn_model *m = c->m;
   const BlobHeader &h = m->hm.hdr;
   const QLayerDesc &d = h.q[h.n_q - 1];
@@ -408,8 +408,22 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   g.out = d_out;
   g.partial = c->d_partial;
   g.partial_ld = g.n_pad;
+  if (d_bits && !d_masks) {  // bit-mask entry points
+    if (g.small || (taps && taps->acc_out)) {
+      if (!c->d_mask) return fail(FDNN_E_STATE, "this context has no byte-mask scratch for a small bit-mask batch");
+      ProfScope ps(m, s, FDNN_PROF_OUTPUT);
+      fdnn::launch_mask_unpack(d_bits, c->d_mask, count, d.rows, s);
+      d_masks = c->d_mask;
+      d_bits = nullptr;
+    } else {
+      d_masks = reinterpret_cast<const int8_t *>(d_bits);  // (non-null = the masked instances; they read mask_bits only)
+    }
+  }
   g.mask = d_masks;
-  if (d_masks && !g.small && !(taps && taps->acc_out)) {
+  if (d_bits) {
+    g.mask_bits = d_bits;
+    g.mask_wpr = (d.rows + 63) / 64;
+  } else if (d_masks && !g.small && !(taps && taps->acc_out)) {
     // large-batch production instances: the mask travels as bits (one pass over the caller's bytes at HBM speed)
     ProfScope ps(m, s, FDNN_PROF_OUTPUT);
     fdnn::launch_mask_pack(d_masks, c->d_mask_bits, count, d.rows, s);
@@ -867,6 +881,32 @@ int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *
   }
   HIP_TRY(hipMemcpyAsync(c->d_mask, masks, size_t(count) * O, hipMemcpyHostToDevice, c->stream));
   int rc = run_output(c, first, count, c->d_mask, c->d_out, c->stream, nullptr);
+  ctx_leave(c, c->stream);
+  if (rc) return rc;
+  return copy_out(out, c->d_out, sizeof(float) * size_t(count) * O, c->stream);
+}
+
+int fdnn_ctx_lazy_output_batch_bits_device(fdnn_ctx *c, int first, int count, const uint64_t *d_bits, float *d_out, void *stream) {
+  if (!c || !d_out || !d_bits) return fail(FDNN_E_ARG, "null argument");
+  DeviceGuard g(c->m->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(ctx_enter(c, s));
+  int rc = run_output(c, first, count, nullptr, d_out, s, nullptr, nullptr, nullptr, nullptr, d_bits);
+  ctx_leave(c, s);
+  return rc;
+}
+
+int fdnn_ctx_lazy_output_batch_bits(fdnn_ctx *c, int first, int count, const uint64_t *bits, float *out) {
+  if (!c || !out || !bits) return fail(FDNN_E_ARG, "null argument");
+  if (c->last < 0) return fail(FDNN_E_STATE, "calculateLazy before calculateUntilOutput");
+  if (first < 0 || count < 0 || first + count > c->n) return fail(FDNN_E_ARG, "frame index outside the context");
+  if (count == 0) return FDNN_OK;
+  DeviceGuard g(c->m->device);
+  const BlobHeader &h = c->m->hm.hdr;
+  const size_t O = size_t(h.out_dim), wpr = (O + 63) / 64;
+  HIP_TRY(ctx_enter(c, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_mask_bits, bits, sizeof(uint64_t) * size_t(count) * wpr, hipMemcpyHostToDevice, c->stream));
+  int rc = run_output(c, first, count, nullptr, c->d_out, c->stream, nullptr, nullptr, nullptr, nullptr, c->d_mask_bits);
   ctx_leave(c, c->stream);
   if (rc) return rc;
   return copy_out(out, c->d_out, sizeof(float) * size_t(count) * O, c->stream);

@@ -289,3 +289,14 @@ def ensure_model_file(path: str, topology: Sequence[int], seed: int = 1, mode: s
         write_model_bin(tmp, synth_net(topology, seed=seed, mode=mode))
         os.replace(tmp, path)
     return path
+
+
+def pack_mask_bits(masks) -> np.ndarray:
+    """Byte masks [n][O] (non-zero = active) -> uint64 [n][ceil(O / 64)], bit b of word w = node 64 w + b: the layout of
+    fdnn_ctx_lazy_output_batch_bits."""
+    m = (np.asarray(masks) != 0)
+    n, O = m.shape
+    wpr = (O + 63) // 64
+    padded = np.zeros((n, wpr * 64), dtype=np.uint8)
+    padded[:, :O] = m
+    return np.packbits(padded, axis=1, bitorder="little").view("<u8").reshape(n, wpr)

@@ -133,6 +133,12 @@ FDNN_API int fdnn_ctx_lazy_output(fdnn_ctx *c, int frame, const int8_t *mask, fl
 FDNN_API int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *masks, float *out);
 FDNN_API int fdnn_ctx_lazy_output_batch_device(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out,
                                                void *stream);
+/* The same with the masks as BITS: bits[count][ceil(output_dim / 64)] 64-bit words, bit b of word w of a row = node
+ * 64 w + b active (bits past output_dim ignored).  A decoder that keeps its active set as a bit set hands it over as it
+ * is: an eighth of the bytes over PCIe / HBM and no pack pass (LazyOutputActivations, dnn.cc:355-392: inactive nodes
+ * contribute exp(0) to the sum and all read 1 / total). */
+FDNN_API int fdnn_ctx_lazy_output_batch_bits(fdnn_ctx *c, int first, int count, const uint64_t *bits, float *out);
+FDNN_API int fdnn_ctx_lazy_output_batch_bits_device(fdnn_ctx *c, int first, int count, const uint64_t *d_bits, float *d_out, void *stream);
 /* Dense output layer over the context's hidden activations
  * (CalculateOutput, dnn.cc:428-454). */
 FDNN_API int fdnn_ctx_output(fdnn_ctx *c, float *out);

@@ -479,3 +479,45 @@ def test_fused_softmax_under_many_streams_and_two_models(net_model_path, tmp_mod
     assert p99 < 3.0 * med + 2e-3, (med, p99)   # (nine callers share one GPU: a call takes ~9 single-stream times; no cliff)
     dnn.delete()
     dnn2.delete()
+
+
+@pytest.mark.parametrize("out_dim,n", [(8000, 10000), (1003, 3000), (8000, 100), (1003, 37)])
+def test_bit_mask_entry_points_equal_the_byte_mask_ones(net_model_path, tmp_models, out_dim, n):
+    """fdnn_ctx_lazy_output_batch_bits[_device]: the LazyContext contract (dnn.cc:355-392) with the active set handed over
+    as bits, one 64-bit word per 64 nodes -- no 80 MB of mask bytes per 10 000-frame step, no pack pass.  Large batches
+    read the words as they are (fused and unfused masked instances, odd output widths), small ones unpack them for the
+    small-batch kernels.  Device and host forms, bit for bit the byte-mask results; a sample against the oracle."""
+    import torch
+
+    if out_dim == 8000:
+        path = net_model_path
+    else:
+        path = os.path.join(tmp_models, f"bits_{out_dim}.bin")
+        F.write_model_bin(path, F.synth_net([432, 256, 256, 256, out_dim], seed=13))
+    x = F.synth_features(n, 432, seed=52)
+    masks = F.generate_masks(n, out_dim, 0.40, 0.03, seed=9)
+    bits = F.pack_mask_bits(masks)
+    assert bits.shape == (n, (out_dim + 63) // 64) and bits.dtype == np.uint64
+    assert int(bits[0, 0]) & 0xff == int(np.packbits(masks[0, :8] != 0, bitorder="little")[0])
+    dnn = api.QuantizedDnn.loadFromFile(path)
+    ctx = dnn.getNewLazyContext(n)
+    xd = torch.from_numpy(x).cuda()
+    md = torch.from_numpy(masks).cuda()
+    bd = torch.from_numpy(bits.view(np.int64)).cuda()
+    a = torch.zeros((n, out_dim), dtype=torch.float32, device="cuda")
+    b = torch.zeros_like(a)
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.calculateUntilOutputDevice(xd.data_ptr(), s)
+    ctx.calculateForOutputNodesBatchDevice(md.data_ptr(), a.data_ptr(), 0, n, s)
+    ctx.calculateForOutputNodesBatchBitsDevice(bd.data_ptr(), b.data_ptr(), 0, n, s)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    k = min(n, 300)   # host form, a range in the middle of the context
+    first = (n - k) // 2
+    got = ctx.calculateForOutputNodesBatchBits(bits[first:first + k], first)
+    assert np.array_equal(got, a[first:first + k].cpu().numpy())
+    idx = np.arange(0, n, max(1, n // 64))
+    want = Oracle(path).lazy(x[idx], masks[idx])
+    assert np.abs(a[torch.from_numpy(idx).cuda()].cpu().numpy() - want).max() <= TIGHT
+    ctx.delete()
+    dnn.delete()
