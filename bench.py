@@ -643,7 +643,26 @@ def main() -> None:
         run(per_call)
         p_rate = run(per_call)
         assert abs(float(bufs[0].sum(1).mean()) - 1.0) < 1e-3
+        # the lazy contract in the same shape: one LazyContext per caller thread (QuantizedDnn.java:72-98), 40 % masks as bits,
+        # rows back compacted (active probabilities + 1 / total per frame over PCIe, rebuilt in the caller's array)
+        ubits = F.pack_mask_bits(F.generate_masks_fast(uf, O, 0.40, 0.03, seed=12))
+        ctxs = [dnn.getNewLazyContext(uf) for _ in range(T)]
+
+        def lazy_call(t):
+            for _ in range(per):
+                ctxs[t].calculateUntilOutput(utt)
+                ctxs[t].calculateForOutputNodesBatchBits(ubits, 0, out=bufs[t])
+
+        run(lazy_call)
+        l_rate = run(lazy_call)
+        for cx in ctxs:
+            cx.delete()
+        assert abs(float(bufs[0].sum(1).mean()) - 1.0) < 1e-3
         serving = {
+            "lazy_40pct_utterances_per_s": round(l_rate, 1),
+            "lazy_vs_dense_per_call": round(l_rate / p_rate, 3),
+            "lazy_note": "one LazyContext per caller thread, calculateUntilOutput + fdnn_ctx_lazy_output_batch_bits per utterance; the "
+                         "rows return compacted (40 % of the floats + one value per frame) and are rebuilt on the host",
             "workload": f"{T} caller threads x {per} utterances of {uf} frames (1 s of speech), host frames in, host soft-max rows out "
                         f"({uf * O * 4 / 1e6:.1f} MB per utterance)",
             "utterances_per_s_through_the_scoring_loop": round(s_rate, 1),
@@ -662,7 +681,7 @@ def main() -> None:
         # WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes); bench.py
         # itself cannot run under rocprof.  Newest round first.
         pmc, pmc_file = {}, None
-        for cand in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for cand in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 pmc_file = cand
@@ -701,14 +720,19 @@ def main() -> None:
                 "share_of_single_stream_step": round(per_step_ms / (single_elapsed / steps * 1e3), 4),
             })
 
-        # single stream: the canonical flavour runs screened (fused chains on the fp32 matrix pipe + exact recomputation of
-        # the few outputs the fusion could change) -- priced against the fp32 MFMA peak; in the scoring loop the overlapped
-        # batches use the all-VALU chain kernel instead
-        add("l0", "layer 0: " + ("l0_mfma_kernel (fused flavour, fp32 MFMA)" if args.l0_fma else
-            "l0_mfma_kernel<screen> + l0_fix_kernel (canonical numerics: fused chains on the fp32 MFMA, "
-            "rigorous error bound, exact unfused recomputation of ~0.4 % of the outputs)"),
-            "mfma", 2.0 * 432 * 2048 * n, 157.3, "TFLOP/s", 1e12,
-            4 * (432 * n + 432 * 2048) + 2048 * n, "l0_mfma_kernel" if args.l0_fma else ("l0_mfma_kernel", "l0_fix_kernel"))
+        # layer 0, canonical flavour: pre-pass (frames -> 24-bit integers as three int8 digit planes), int8 screening kernel
+        # (six exact digit products on the int8 MFMA, sampled chain sums, rigorous bound, flags), exact recomputation of the
+        # ~0.35 % of outputs whose table byte the approximation could change.  Priced against the int8 MFMA peak with the
+        # digit products actually issued (6 x 2 x 512 x 2048 ops per frame: the layer's own 2 x 432 x 2048 fp32 flop per frame
+        # would read 19 TFLOP/s); the fused flavour still runs on the fp32 MFMA.
+        if args.l0_fma:
+            add("l0", "layer 0: l0_mfma_kernel (fused flavour, fp32 MFMA)", "mfma", 2.0 * 432 * 2048 * n, 157.3, "TFLOP/s", 1e12,
+                4 * (432 * n + 432 * 2048) + 2048 * n, "l0_mfma_kernel")
+        else:
+            add("l0", "layer 0: l0_digits_kernel + l0_split_kernel + l0_fix_list_kernel (canonical numerics: exact int8 digit products on the "
+                "int8 MFMA, rigorous error bound, exact unfused recomputation of ~0.35 % of the outputs)",
+                "mfma", 6 * 2.0 * 512 * 2048 * n, INT8_PEAK_TOPS, "TOP/s", 1e12,
+                4 * (432 * n + 432 * 2048) + 2048 * n, ("l0_digits_kernel", "l0_split_kernel", "l0_fix_list_kernel"))
         add("hidden_gemm", "qgemm_kernel<hidden> (int8 MFMA 32x32x32, 2048x2048 layer + dequant/bias/sigmoid-table epilogue)",
             "mfma", 2.0 * 2048 * 2048 * n, INT8_PEAK_TOPS, "TOP/s", 1e12, 2048 * 2048 + 2 * n * 2048, "qgemm_kernel hidden")
         fused_out = not prof["normalize"]["launches"]
@@ -722,7 +746,7 @@ def main() -> None:
         gemm = next(k for k in kinds if k["kernel"].startswith("qgemm_kernel<hidden>"))
         rocprof = None
         try:  # the same fractions from the committed rocprofv3 averages (tools/profile_round.sh)
-            rocprof = json.load(open(os.path.join(ROOT, "profiles", "r03_roofline.json")))
+            rocprof = json.load(open(os.path.join(ROOT, "profiles", "r04_roofline.json")))
         except Exception:
             pass
         value = world * n * steps / elapsed
@@ -755,13 +779,14 @@ def main() -> None:
             "single_stream": {"frames_per_s": round(world * n * steps / single_elapsed, 1), "ms_per_step": round(single_elapsed / steps * 1e3, 4),
                               "note": "the same K steps as back-to-back fdnn_calculate_device calls on one stream (no overlap between steps)"},
             "roofline": dict(dominant, note="largest share of the step; times from HIP events on the launch stream, which add ~4 us per "
-                                            "bracketed launch -- profiles/r03_roofline.json holds the rocprofv3 averages"),
+                                            "bracketed launch -- profiles/r04_roofline.json holds the rocprofv3 averages"),
             "roofline_int8_gemm": gemm,
             "roofline_kernels": kinds,
             "end_to_end": {"bound": "mfma", "achieved": round(value / world, 1), "peak": round(ROOFLINE_FRAMES_PER_S, 1), "unit": "frames/s per GPU",
                            "frac": round(value / world / ROOFLINE_FRAMES_PER_S, 4),
-                           "note": "5 POP/s int8 / 83.1 M int8 ops per frame; layer 0 (2 % of the MACs, fp32) is not int8-MFMA work and "
-                                   "takes about a third of the step; the 32 KB per frame of probabilities leave from inside the output kernel"},
+                           "note": "5 POP/s int8 / 83.1 M int8 ops per frame (layers 1..7); layer 0 (2 % of the MACs, fp32 in the reference) runs as "
+                                   "six int8 digit products + an exact fix and takes about a fifth of the step; the 32 KB per frame of "
+                                   "probabilities leave from inside the output kernel"},
             "traffic_source": pmc_file,
             "rocprof": rocprof,
             "setup": {"clock_ramp_steps": ramp_steps, "clock_ramp_s": args.clock_ramp_s,

@@ -224,13 +224,17 @@ class LazyContext:
         return out
 
     # device-resident forms (raw device pointers, e.g. ``tensor.data_ptr()``; enqueued on ``stream``)
-    def calculateForOutputNodesBatchBits(self, bits, first: int = 0) -> np.ndarray:
-        """Batched lazy output with the masks as bits: uint64 [count][ceil(O / 64)] (formats.pack_mask_bits)."""
+    def calculateForOutputNodesBatchBits(self, bits, first: int = 0, out=None) -> np.ndarray:
+        """Batched lazy output with the masks as bits: uint64 [count][ceil(O / 64)] (formats.pack_mask_bits).
+        ``out``: a resident float32 [count][O] array to fill (a JVM caller's float[] would be)."""
         b = np.ascontiguousarray(bits, dtype=np.uint64)
         O = self.dnn.outputDimension()
         if b.ndim != 2 or b.shape[1] != (O + 63) // 64:
             raise ValueError("bits must be [count][ceil(outputDimension / 64)] uint64")
-        out = np.empty((b.shape[0], O), dtype=np.float32)
+        if out is None:
+            out = np.empty((b.shape[0], O), dtype=np.float32)
+        elif out.dtype != np.float32 or out.shape != (b.shape[0], O) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous float32 [count][outputDimension] array")
         _check(lib().fdnn_ctx_lazy_output_batch_bits(self.handle, first, b.shape[0], b.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
         return out
 

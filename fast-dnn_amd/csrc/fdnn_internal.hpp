@@ -94,6 +94,8 @@ struct fdnn_ctx {
   uint32_t *d_fuse_cnt = nullptr;   // {arrived, left} per frame tile; zero between launches
   uint32_t *d_fuse_flag = nullptr;  // per tile: "gave up waiting" (fuse_cleanup_kernel); zero between launches
   uint64_t *d_mask_bits = nullptr;  // [n][ceil(O/64)] the batched lazy call's mask as bits (launch_mask_pack)
+  float *d_comp = nullptr;          // host lazy batches: compacted result rows (allocated on first use)
+  size_t comp_floats = 0;
   int last = -1;                  // d_act index holding the last hidden layer, -1 = not computed
   bool pooled = false;
   bool no_fuse = false;           // this call must not use the fused soft-max

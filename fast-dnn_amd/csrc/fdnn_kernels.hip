@@ -212,7 +212,42 @@ __global__ __launch_bounds__(256) void mask_unpack_kernel(const uint64_t *bits, 
   }
 }
 
+// Lazy results for a host caller, compacted: every inactive node of a row reads the same 1 / total (exp(0) terms,
+// dnn.cc:366-369, :389), so only the active nodes' probabilities and that one value have to cross PCIe.
+//   comp[f][0] = the row's inactive value (0 if the row has no inactive node), comp[f][1 + r] = probability of the row's r-th
+//   active node, in node order.  One wave per frame: lane = node within the 64-node word, coalesced reads, dense writes.
+__global__ __launch_bounds__(256) void lazy_compact_kernel(const float *out, const uint64_t *bits, float *comp, int n, int rows, int wpr, int stride) {
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (f >= n) return;
+  const float *row = out + static_cast<size_t>(f) * rows;
+  float *dst = comp + static_cast<size_t>(f) * stride;
+  int at = 0;
+  float inactive = 0.0f;
+  bool have = false;
+  for (int w = 0; w < wpr; ++w) {
+    const uint64_t word = bits[static_cast<size_t>(f) * wpr + w];  // (wave-uniform)
+    const int node = 64 * w + lane;
+    const bool in = node < rows, on = in && ((word >> lane) & 1ull);
+    const float v = in ? row[node] : 0.0f;
+    if (on) dst[1 + at + __popcll(word & ((1ull << lane) - 1ull))] = v;
+    const uint64_t valid = rows - 64 * w >= 64 ? ~0ull : ((1ull << (rows - 64 * w)) - 1ull);
+    at += __popcll(word & valid);
+    if (!have) {
+      const uint64_t off = ~word & valid;
+      if (off) {
+        inactive = __shfl(v, __ffsll(static_cast<long long>(off)) - 1);
+        have = true;
+      }
+    }
+  }
+  if (lane == 0) dst[0] = inactive;
+}
+
 }  // namespace
+
+void launch_lazy_compact(const float *out, const uint64_t *bits, float *comp, int n, int rows, int stride, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(lazy_compact_kernel, dim3((n + 3) / 4), dim3(256), 0, s, out, bits, comp, n, rows, (rows + 63) / 64, stride);
+}
 
 void launch_mask_unpack(const uint64_t *bits, int8_t *mask, int n, int rows, hipStream_t s) {
   const long long total = static_cast<long long>(n) * rows;

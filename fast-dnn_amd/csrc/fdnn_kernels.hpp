@@ -130,6 +130,8 @@ void launch_qgemm_output(const QGemmParams &p, hipStream_t s);
 // output GEMM's epilogue.
 void launch_mask_pack(const int8_t *mask, uint64_t *bits, int n, int rows, hipStream_t s);
 void launch_mask_unpack(const uint64_t *bits, int8_t *mask, int n, int rows, hipStream_t s);
+// comp[f][0] = row f's inactive value, comp[f][1 + r] = probability of its r-th active node (rows of `stride` floats)
+void launch_lazy_compact(const float *out, const uint64_t *bits, float *comp, int n, int rows, int stride, hipStream_t s);
 
 // dst[f][:] = out[f][:] / sum_t partial[t][f]   (dst == out: in place; dst may be host-mapped)
 // background: a small fixed grid walking the rows (server loop: runs under the next batch's layer 0)

@@ -147,6 +147,7 @@ void destroy_ctx(fdnn_ctx *c) {
   hipFree(c->d_scr_count);
   hipFree(c->d_xd);
   hipFree(c->d_xstat);
+  hipFree(c->d_comp);
   hipFree(c->d_glist);
   hipFree(c->d_glist_count);
   hipFree(c->d_scr_list);
@@ -858,6 +859,8 @@ int fdnn_ctx_lazy_output_batch_device(fdnn_ctx *c, int first, int count, const i
   return rc;
 }
 
+static int lazy_copy_out(fdnn_ctx *c, int count, const uint64_t *d_bits, const uint64_t *bits, float *out, hipStream_t s);
+
 int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *masks, float *out) {
   if (!c || !out || !masks) return fail(FDNN_E_ARG, "null argument");
   if (c->last < 0) return fail(FDNN_E_STATE, "calculateLazy before calculateUntilOutput");
@@ -881,9 +884,21 @@ int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *
   }
   HIP_TRY(hipMemcpyAsync(c->d_mask, masks, size_t(count) * O, hipMemcpyHostToDevice, c->stream));
   int rc = run_output(c, first, count, c->d_mask, c->d_out, c->stream, nullptr);
+  if (!rc) {
+    // the same masks as bits, for the compacted return (lazy_copy_out): on the host while the GPU computes, on the device
+    // by the pack kernel (a large batch's output kernel has run it already)
+    const size_t wpr = (O + 63) / 64;
+    std::vector<uint64_t> hb(size_t(count) * wpr, 0);
+    for (int f = 0; f < count; ++f) {
+      const int8_t *mrow = masks + size_t(f) * O;
+      uint64_t *brow = hb.data() + size_t(f) * wpr;
+      for (size_t k = 0; k < O; ++k) brow[k >> 6] |= uint64_t(mrow[k] != 0) << (k & 63);
+    }
+    fdnn::launch_mask_pack(c->d_mask, c->d_mask_bits, count, int(O), c->stream);
+    rc = lazy_copy_out(c, count, c->d_mask_bits, hb.data(), out, c->stream);
+  }
   ctx_leave(c, c->stream);
-  if (rc) return rc;
-  return copy_out(out, c->d_out, sizeof(float) * size_t(count) * O, c->stream);
+  return rc;
 }
 
 int fdnn_ctx_lazy_output_batch_bits_device(fdnn_ctx *c, int first, int count, const uint64_t *d_bits, float *d_out, void *stream) {
@@ -894,6 +909,57 @@ int fdnn_ctx_lazy_output_batch_bits_device(fdnn_ctx *c, int first, int count, co
   int rc = run_output(c, first, count, nullptr, d_out, s, nullptr, nullptr, nullptr, nullptr, d_bits);
   ctx_leave(c, s);
   return rc;
+}
+
+// Lazy results to a host caller.  Every inactive node of a row reads the same 1 / total (dnn.cc:366-369, :389), so what
+// crosses PCIe is the active nodes' probabilities and that one value per frame (lazy_compact_kernel); the rows are
+// rebuilt on the host inside the caller's array: the compacted block lands in its tail, and the rows are expanded front to
+// back (row f's place never reaches the compacted rows of later frames; its own is copied aside first).  d_bits: the
+// masks of the `count` frames on the device; bits: the same on the host.  With mostly active masks (> 3/4) the plain copy
+// is used.  Synchronises the stream.
+static int lazy_copy_out(fdnn_ctx *c, int count, const uint64_t *d_bits, const uint64_t *bits, float *out, hipStream_t s) {
+  const size_t O = size_t(c->m->hm.hdr.out_dim), wpr = (O + 63) / 64;
+  static const bool no_compact = std::getenv("FDNN_LAZY_NO_COMPACT") != nullptr;
+  size_t most = 0;
+  const uint64_t tail_mask = (O & 63) ? ((uint64_t(1) << (O & 63)) - 1) : ~uint64_t(0);
+  for (int f = 0; f < count; ++f) {
+    size_t k = 0;
+    const uint64_t *row = bits + size_t(f) * wpr;
+    for (size_t w = 0; w + 1 < wpr; ++w) k += size_t(__builtin_popcountll(row[w]));
+    k += size_t(__builtin_popcountll(row[wpr - 1] & tail_mask));
+    most = std::max(most, k);
+  }
+  const size_t stride = most + 1;
+  if (no_compact || stride * 4 > O * 3) return copy_out(out, c->d_out, sizeof(float) * size_t(count) * O, s);
+  if (c->comp_floats < size_t(count) * stride) {
+    if (c->d_comp) HIP_TRY(hipFree(c->d_comp));
+    c->d_comp = nullptr;
+    c->comp_floats = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_comp), sizeof(float) * size_t(count) * stride));
+    c->comp_floats = size_t(count) * stride;
+  }
+  fdnn::launch_lazy_compact(c->d_out, d_bits, c->d_comp, count, int(O), int(stride), s);
+  float *land = out + size_t(count) * O - size_t(count) * stride;
+  HIP_TRY(hipMemcpyAsync(land, c->d_comp, sizeof(float) * size_t(count) * stride, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  std::vector<float> mine(stride);
+  for (int f = 0; f < count; ++f) {
+    std::memcpy(mine.data(), land + size_t(f) * stride, sizeof(float) * stride);
+    float *row = out + size_t(f) * O;
+    std::fill(row, row + O, mine[0]);
+    const uint64_t *brow = bits + size_t(f) * wpr;
+    size_t at = 1;
+    for (size_t w = 0; w < wpr; ++w) {
+      uint64_t word = brow[w];
+      if (w + 1 == wpr) word &= tail_mask;
+      while (word) {
+        const int b = __builtin_ctzll(word);
+        word &= word - 1;
+        row[64 * w + size_t(b)] = mine[at++];
+      }
+    }
+  }
+  return FDNN_OK;
 }
 
 int fdnn_ctx_lazy_output_batch_bits(fdnn_ctx *c, int first, int count, const uint64_t *bits, float *out) {
@@ -907,9 +973,9 @@ int fdnn_ctx_lazy_output_batch_bits(fdnn_ctx *c, int first, int count, const uin
   HIP_TRY(ctx_enter(c, c->stream));
   HIP_TRY(hipMemcpyAsync(c->d_mask_bits, bits, sizeof(uint64_t) * size_t(count) * wpr, hipMemcpyHostToDevice, c->stream));
   int rc = run_output(c, first, count, nullptr, c->d_out, c->stream, nullptr, nullptr, nullptr, nullptr, c->d_mask_bits);
+  if (!rc) rc = lazy_copy_out(c, count, c->d_mask_bits, bits, out, c->stream);
   ctx_leave(c, c->stream);
-  if (rc) return rc;
-  return copy_out(out, c->d_out, sizeof(float) * size_t(count) * O, c->stream);
+  return rc;
 }
 
 int fdnn_ctx_lazy_output(fdnn_ctx *c, int frame, const int8_t *mask, float *out) {

@@ -521,3 +521,45 @@ def test_bit_mask_entry_points_equal_the_byte_mask_ones(net_model_path, tmp_mode
     assert np.abs(a[torch.from_numpy(idx).cuda()].cpu().numpy() - want).max() <= TIGHT
     ctx.delete()
     dnn.delete()
+
+
+@pytest.mark.parametrize("out_dim,n,frac", [(8000, 100, 0.4), (8000, 1000, 0.4), (1003, 300, 0.1), (1003, 64, 0.9), (130, 50, 0.5)])
+def test_host_lazy_batches_return_compacted_rows(net_model_path, tmp_models, out_dim, n, frac):
+    """A host caller of the batched lazy contract gets its rows back compacted: inactive nodes all read 1 / total
+    (dnn.cc:366-369, :389), so only the active probabilities and that value cross PCIe and the rows are rebuilt inside the
+    caller's array.  Byte and bit forms against LazyOutputActivations (dnn.cc:355-392), with rows that are all active, all
+    inactive, and one node short of either; identical to the uncompacted device result bit for bit."""
+    import torch
+
+    if out_dim == 8000:
+        path = net_model_path
+    else:
+        path = os.path.join(tmp_models, f"compact_{out_dim}.bin")
+        F.write_model_bin(path, F.synth_net([432, 128, 128, 128, out_dim], seed=17))
+    x = F.synth_features(n, 432, seed=53)
+    masks = F.generate_masks(n, out_dim, frac, 0.05, seed=3)
+    masks[0] = 1
+    masks[1] = 0
+    masks[2] = 1
+    masks[2, out_dim - 1] = 0
+    masks[3] = 0
+    masks[3, 0] = 1
+    dnn = api.QuantizedDnn.loadFromFile(path)
+    ctx = dnn.getNewLazyContext(n)
+    ctx.calculateUntilOutput(x)
+    got = ctx.calculateForOutputNodesBatch(masks)
+    want = Oracle(path).lazy(x, masks)
+    assert np.abs(got - want).max() <= TIGHT
+    got_bits = ctx.calculateForOutputNodesBatchBits(F.pack_mask_bits(masks))
+    assert np.array_equal(got, got_bits)
+    # the device-resident (uncompacted) result of the same call
+    md = torch.from_numpy(masks).cuda()
+    od = torch.zeros((n, out_dim), dtype=torch.float32, device="cuda")
+    ctx.calculateForOutputNodesBatchDevice(md.data_ptr(), od.data_ptr(), 0, n, 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(od.cpu().numpy(), got)
+    # a sub-range of the context
+    sub = ctx.calculateForOutputNodesBatch(masks[10:40], 10)
+    assert np.array_equal(sub, got[10:40])
+    ctx.delete()
+    dnn.delete()

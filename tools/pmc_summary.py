@@ -19,6 +19,9 @@ NAMES = {
     "l0_chain_kernel": "l0_chain_kernel (fp32 layer 0, canonical flavour, one chain per pass)",
     "l0_image_kernel": "l0_image_kernel (layer-0 frame image: shift/scale + chain-major transpose)",
     "l0_mfma_kernel": "l0_mfma_kernel (fp32 layer 0 on the matrix pipe: screened canonical / fused flavour)",
+    "l0_split_kernel": "l0_split_kernel (int8 screening of layer 0)",
+    "l0_digits_kernel": "l0_digits_kernel (frames -> int8 digit planes + row constants)",
+    "l0_fix_list_kernel": "l0_fix_list_kernel (exact recomputation of the flagged outputs, one list per launch)",
     "l0_fix_kernel": "l0_fix_kernel (exact recomputation of the screened outputs)",
     "l0_xnorm_kernel": "l0_xnorm_kernel (frame norms)",
     "normalize_kernel": "normalize_kernel (soft-max scale)",
