@@ -1021,23 +1021,27 @@ __device__ __forceinline__ float quad_bcast(float v) {
 // and scale applied, w) -- and each step's quad is then handed round with quad broadcasts, chain c keeping element c.
 // (One lane per output reading 16 bytes of its own rows per load is address-processing bound: every (output, k-quad) is
 // its own 16-byte segment -- 66 us for 0.4 % of the outputs.)
+#ifndef FDNN_L0_FIX_DEPTH
+#define FDNN_L0_FIX_DEPTH 3  // operand quads per lane in flight per round of the exact recomputation
+#endif
 // One listed output, four lanes = four chains (lane c is chain c; all four lanes of a quad must call this together).
 __device__ __forceinline__ void fix_one_output(const L0Params &p, const float *sh_s, const float *sc_s, int f, int node, bool live, int c, int quads) {
   typedef float v4f __attribute__((ext_vector_type(4)));
   const float *xr = p.x + static_cast<size_t>(live ? f : 0) * p.D, *wr = p.w + static_cast<size_t>(live ? node : 0) * p.D;
   float acc = 0.0f;
-  // twelve k-steps per round: the three quads per lane (and operand) are all requested before the first is used --
-  // with one quad in flight per lane the walk is a chain of 27 L2 round trips
-  for (int q0 = 0; q0 < quads; q0 += 12) {
-    v4f xq[3], wq[3];
+  // 4 NB k-steps per round: the NB quads per lane (and operand) are all requested before the first is used -- the walk is
+  // a chain of L2 round trips, one per round (NB = 3: nine of them for D = 432)
+  constexpr int NB = FDNN_L0_FIX_DEPTH;
+  for (int q0 = 0; q0 < quads; q0 += 4 * NB) {
+    v4f xq[NB], wq[NB];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < NB; ++b) {
       const int q = min(q0 + 4 * b + c, quads - 1);  // (a clamped quad is never consumed: its step is skipped below)
       xq[b] = *reinterpret_cast<const v4f *>(xr + 4 * q);
       wq[b] = *reinterpret_cast<const v4f *>(wr + 4 * q);
     }
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
+    for (int b = 0; b < NB; ++b) {
       const int q = min(q0 + 4 * b + c, quads - 1);
       xq[b] = (xq[b] + *reinterpret_cast<const v4f *>(sh_s + 4 * q)) * *reinterpret_cast<const v4f *>(sc_s + 4 * q);  // add, then multiply
     }
@@ -1050,9 +1054,10 @@ __device__ __forceinline__ void fix_one_output(const L0Params &p, const float *s
     const float pr = xs * wv; /* this file is compiled -ffp-contract=off: product and sum round separately */                \
     acc = acc + pr;           /* (dnn.cc:233-238) */                                                                          \
   }
-    FDNN_FIX_STEP(0, 0) FDNN_FIX_STEP(0, 1) FDNN_FIX_STEP(0, 2) FDNN_FIX_STEP(0, 3)
-    FDNN_FIX_STEP(1, 0) FDNN_FIX_STEP(1, 1) FDNN_FIX_STEP(1, 2) FDNN_FIX_STEP(1, 3)
-    FDNN_FIX_STEP(2, 0) FDNN_FIX_STEP(2, 1) FDNN_FIX_STEP(2, 2) FDNN_FIX_STEP(2, 3)
+#pragma unroll
+    for (int B = 0; B < NB; ++B) {
+      FDNN_FIX_STEP(B, 0) FDNN_FIX_STEP(B, 1) FDNN_FIX_STEP(B, 2) FDNN_FIX_STEP(B, 3)
+    }
 #undef FDNN_FIX_STEP
   }
   const float c0 = quad_bcast<0>(acc), c1 = quad_bcast<1>(acc), c2 = quad_bcast<2>(acc), c3 = quad_bcast<3>(acc);

@@ -12,18 +12,19 @@
 //   node row n:   W_k = rint(w_k c_n)  likewise (model load, in double)
 //   X = 65536 X1 + 256 X2 + X3,  W likewise, balanced digits in [-128, 127]   -> three int8 planes per operand
 //   sum_k X_k W_k = 2^32 [P0 + 2^-8 P1 + 2^-16 P2 + 2^-24 P3 + 2^-32 P4],   P_o = sum over digit pairs of order o
-//   P0 = X1.W1, P1 = X1.W2 + X2.W1, P2 = X1.W3 + X2.W2 + X3.W1, P3 = X2.W3 + X3.W2: eight int8 MFMA products, int32
-//   accumulators, no rounding anywhere; P4 = X3.W3 (|P4| <= 2^14 D) is dropped and bounded.
+//   P0 = X1.W1, P1 = X1.W2 + X2.W1, P2 = X1.W3 + X2.W2 + X3.W1: six int8 MFMA products, int32 accumulators, no rounding
+//   anywhere; P3 = X2.W3 + X3.W2 and P4 = X3.W3 are dropped and bounded (|X2|, |X3| <= 128: |P3| <= 128 (||W2||_1 +
+//   ||W3||_1), |P4| <= 128 ||W3||_1).  (With P3 kept -- eight products -- 0.27 % of the outputs are flagged instead of
+//   0.35 %, at a quarter more matrix work and a fourth accumulator set: profiles/LABBOOK.md.)
 //
-// lin~ = sigma V + bias,  V = P0 + 2^-8 P1 + 2^-16 P2 + 2^-24 P3,  sigma = 2^32 / (c_f c_n).  What separates lin~ from the
-// reference's lin is then (a) the quantisation x c_f - X, w c_n - W, (b) P4, (c) a few float roundings of the final
+// lin~ = sigma V + bias,  V = P0 + 2^-8 P1 + 2^-16 P2,  sigma = 2^32 / (c_f c_n).  What separates lin~ from the
+// reference's lin is then (a) the quantisation x c_f - X, w c_n - W, (b) P3 + P4, (c) a few float roundings of the final
 // evaluation -- all bounded per row at no cost -- and (d) the REFERENCE's own rounding errors
 //     |lin_ref - (sum_k x_k w_k + bias)|  <=  u (sum_{c,j} |s'_{c,j}| + S + 3 sum_c |l_c| + |lin_ref|),   S = sum_k |x_k w_k|,
 // s'_{c,j} its partial sums (telescoping, exact; u = 2^-24).  Partial sums are random-walk sized and S is not, so as in
-// round 2 the kernel SAMPLES them: the k order of the planes is chain-major (chain c = positions c J .. c J + J - 1,
-// J = D / 4), P0 is accumulated chain by chain (a chunk of 32 that straddles a chain boundary is issued as two MFMAs
-// with complementary byte masks on the frame operand), and after every MFMA of P0 the accumulator is added, as |.|, to
-// A.  Between two samples a, b of a chain, at most w = 32 steps apart,
+// round 2 the kernel SAMPLES them: the k order of the planes is chain-major, every chain padded with zeros to a whole
+// number of 32-position chunk pairs (432 -> 4 x 128 positions), P0 is accumulated chain by chain, and after every MFMA
+// of P0 the accumulator is added, as |.|, to A.  Between two samples a, b of a chain, at most w = 32 steps apart,
 //     |s'_j| <= min(|s'_a| + F_j, |s'_b| + B_j),  F_j + B_j = (window's sum of |fl(t)| + |eps|)   =>
 //     sum_j |s'_j| <= (w/2)(|s'_a| + |s'_b|) + (w/2) S_window       (two-sided; round 2 used the one-sided form)
 // and a sample of P0 differs from the reference's partial sum by the low digits: |X W - 2^32 X1 W1| <= 2^32 0.502
@@ -31,13 +32,13 @@
 //     E = sigma (kA A + a_f + b_n) + kS ||x||_2 ||w||_2 + 10 u |bias|
 //       kA = (w + 3) u        A = sum over samples of |P0 partial|     (+3: the three combining adds and the bias add)
 //       kS = (w/2 + 2) u      (+1: the products' own roundings; +1: the x c_f multiply's rounding, u |X W|)
-//       a_f = u (w+3) m 0.502 ||X1||_1 + 2^-32 (0.5 ||X||_1 + 0.5 D + 2^14 D) + u 2^8 D     (per frame, pre-pass)
-//       b_n = u (w+3) m 0.502 ||W||_1 / 65536 + 2^-32 0.5 ||W||_1                          (per node, model load)
-//       m = samples per chain <= ceil(J / 32) + 2
+//       a_f = u (w+3) m 0.502 ||X1||_1 + 2^-32 (0.5 ||X||_1 + 0.5 D) + u 2^8 D                          (per frame, pre-pass)
+//       b_n = u (w+3) m 0.502 ||W||_1 / 65536 + 2^-32 0.5 ||W||_1 + 2^-24 128 (||W2||_1 + ||W3||_1) + 2^-32 128 ||W3||_1   (per node, model load)
+//       m = samples per chain = chunks per chain + 1
 // all evaluated with upward slack; |fl(100 lin_ref) - fl(100 lin~)| <= Dd = 100.001 E + 12 u |100 lin~|.  An output is
 // flagged when a half-integer lies within Dd of 100 lin~ and the table bytes on both sides differ (ties included; NaN /
-// degenerate rows flag everything); l0_fix_kernel (fdnn_l0.hip) recomputes the flagged outputs with the exact chains.
-// Measured on the 10 000-frame bench batch: see DESIGN.md section 5.
+// degenerate rows flag everything); l0_fix_list_kernel (fdnn_l0.hip) recomputes the flagged outputs with the exact chains.
+// Measured on the 10 000-frame bench batch: DESIGN.md section 5, profiles/LABBOOK.md.
 #include <atomic>
 #include <cmath>
 #include <cstdlib>

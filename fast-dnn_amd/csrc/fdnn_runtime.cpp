@@ -228,7 +228,7 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_out_pin), sizeof(float) * kPinFrames * h.out_dim, hipHostMallocMapped);
   if (e == hipSuccess && !lean) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_out_pin), c->h_out_pin, 0);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming | hipEventDisableSystemFence);  // (orders streams of one device only: no system-scope flush per record)
   if (e != hipSuccess) {
     std::string msg = std::string("context allocation for ") + std::to_string(n) + " frames: " + hipGetErrorString(e);
     destroy_ctx(c);
@@ -454,7 +454,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
       // freely (they wait for nothing).  Two PROCESSES on one GPU cannot be chained: FDNN_FUSE_NORM=0.
       FuseChain &fc = fuse_chain(m->device);
       std::lock_guard<std::mutex> lk(fc.mu);
-      if (!fc.ev) HIP_TRY(hipEventCreateWithFlags(&fc.ev, hipEventDisableTiming));
+      if (!fc.ev) HIP_TRY(hipEventCreateWithFlags(&fc.ev, hipEventDisableTiming | hipEventDisableSystemFence));
       if (fc.recorded) HIP_TRY(hipStreamWaitEvent(s, fc.ev, 0));  // (a wait on the stream's own last record is free)
       fdnn::launch_qgemm_output(g, s);
       HIP_TRY(hipEventRecord(fc.ev, s));

@@ -454,8 +454,8 @@ int fdnn_server_create(fdnn_model *m, int max_frames, int depth, fdnn_server **o
     rc = fdnn::make_ctx(m, max_frames, &sl.ctx, /*lean=*/true);
     if (rc) break;
     e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.gemm_done, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.tail_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.gemm_done, hipEventDisableTiming | hipEventDisableSystemFence);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.tail_done, hipEventDisableTiming | hipEventDisableSystemFence);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.staged, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.done, hipEventDisableTiming);
   }

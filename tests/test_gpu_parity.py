@@ -647,3 +647,30 @@ def test_kaldi_text_model_through_the_hip_path(tmp_path):
     ref = CV.float_forward(CV.align(got, 4, 16), x)
     assert CV.quantization_report(ref, dnn.calculate(x))["max_abs_diff"] < 0.1
     dnn.delete()
+
+
+def test_one_frame_lazy_call_on_a_net_the_small_kernels_cannot_take(tmp_models):
+    """The per-frame JNI call on a net whose last hidden layer is wider than the small-batch GEMM kernel's 2048 inputs: the
+    one-frame block then goes through the large-tile output GEMM behind a mask_pack pass that reads the host-mapped
+    pinned staging (fdnn_ctx_lazy_output_batch, count <= 8).  Against LazyOutputActivations (dnn.cc:355-392), and
+    bit for bit what the 24-frame batch gives for the same frames."""
+    import os
+
+    p = os.path.join(tmp_models, "wide_hidden.bin")
+    F.write_model_bin(p, F.synth_net([40, 2304, 2304, 2304, 300], seed=29, w_std=0.02))
+    n = 24
+    x = F.synth_features(n, 40, seed=30, pad_from=None)
+    masks = F.generate_masks(n, 300, 0.40, 0.05, seed=6)
+    masks[1] = 0
+    masks[2] = 1
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    ctx = dnn.getNewLazyContext(n)
+    ctx.calculateUntilOutput(x)
+    batch = ctx.calculateForOutputNodesBatch(masks)
+    rows = np.stack([ctx.calculateForOutputNodes(masks[i]) for i in range(n)])
+    assert (rows == batch).all()
+    want = Oracle(p).lazy(x, masks)
+    assert np.abs(rows - want).max() <= TIGHT
+    assert np.abs(dnn.calculate(x) - Oracle(p).calculate(x)).max() <= TIGHT
+    ctx.delete()
+    dnn.delete()

@@ -373,7 +373,8 @@ def test_both_screening_kernels_are_bit_exact(net_model_path, kind):
     dnn = api.QuantizedDnn.loadFromFile(net_model_path)
     dnn.setInputLayerKernel(kind)
     got, recomputed = dnn.layer0(x)
-    if not os.environ.get("FDNN_L0_NO_SCREEN"):
+    screened = not os.environ.get("FDNN_L0_NO_SCREEN") and not (kind == 4 and os.environ.get("FDNN_L0_NO_SPLIT"))
+    if screened:  # (diagnosis switches take the screening paths out: the bytes below must still be right)
         assert 0 < recomputed < 0.05 * n * 2048, recomputed
     orc = Oracle(net_model_path)
     for lo in range(0, n, 512):
@@ -405,7 +406,8 @@ def test_int8_screening_with_hostile_rows(net_model_path):
     dnn = api.QuantizedDnn.loadFromFile(net_model_path)
     dnn.setInputLayerKernel(4)
     got, recomputed = dnn.layer0(x)
-    assert recomputed > 0
+    if not os.environ.get("FDNN_L0_NO_SCREEN") and not os.environ.get("FDNN_L0_NO_SPLIT"):
+        assert recomputed > 0
     orc = Oracle(net_model_path)
     with np.errstate(all="ignore"):
         _, t = orc.calculate(x, taps=True)

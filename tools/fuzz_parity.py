@@ -18,7 +18,7 @@ TIGHT = 2e-6
 t0 = time.time()
 worst = 0.0
 for case in range(cases):
-    in_dim = int(rng.choice([4, 8, 12, 40, 44, 100, 432]))
+    in_dim = int(rng.choice([4, 8, 12, 40, 44, 64, 100, 132, 256, 432, 496]))  # (64 .. 496: the int8 screening of layer 0 from 640 frames up)
     hidden = int(rng.choice([16, 32, 48, 64, 96, 128, 192, 256, 272, 512, 1024]))
     n_hidden = int(rng.integers(3, 6))
     out = int(rng.choice([1, 3, 4, 31, 32, 33, 100, 257, 1000, 1001, 2048]))
