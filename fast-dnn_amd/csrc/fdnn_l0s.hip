@@ -659,9 +659,10 @@ void launch_l0_split(const L0Params &p, hipStream_t s) {
   (void)hipGetDevice(&dev);
   const unsigned long long dev_bit = 1ull << (dev & 63);
   const int dig_lds = (kDigFrames * (p.D + 1) + kDigFrames) * 4;
-  // 128-node tiles, one 512-thread workgroup per CU -- unless the batch is so small that they would leave half the chip idle
-  // (up to 128 tiles: 1 024 frames on a 2048-node layer): then 64-node tiles, twice as many workgroups of half the size
-  // (measured equal where both fill the chip: 99.2 vs 97.7 us at 10 000 frames).  FDNN_L0S_WN=1|2 forces one.
+  // 128-node tiles, one 512-thread workgroup per CU; batches so small that those would leave half the chip idle (up to 128
+  // tiles: 1 024 frames on a 2048-node layer) take 64-node tiles, twice as many workgroups of half the size.  Measured
+  // equal both where both fill the chip (99.2 vs 97.7 us at 10 000 frames) and below (layer 0 at 1 000 frames 40.2 vs 40.4 us:
+  // one tile's latency -- 16 chunks and a 32-output-per-lane epilogue per wave -- either way).  FDNN_L0S_WN=1|2 forces one.
   static const int wn_forced = [] {
     const char *e = std::getenv("FDNN_L0S_WN");
     return e ? std::atoi(e) : 0;
