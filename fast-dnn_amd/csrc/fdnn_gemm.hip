@@ -556,8 +556,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
       const int ff = fw0 + 32 * ni + frow, grp = ncol0 >> 6;
       fmw[ni] = (MASKED && ff < p.n && grp < p.mask_wpr) ? p.mask_bits[static_cast<size_t>(ff) * p.mask_wpr + grp] : 0ull;
     }
-#pragma unroll
-    for (int ni = 0; ni < NF; ++ni) {
+    // Round 4: the exchange in TWO PARTS.  A frame's row sum is complete as soon as its own 32-frame block has gone through
+    // phase 1, so the sums of the blocks ni < kSplit are published (and their arrival counted) before the remaining blocks'
+    // exp work; by the time a workgroup has finished phase 1 its siblings' first part has long been published, and while it
+    // scales and stores the first part's blocks their second part arrives: of the wait for the slowest of the MT siblings
+    // only what exceeds that slack is left.  Same sums, same tree, same bits.  Counters per frame tile:
+    // {arrived part 0, arrived part 1, left, -}; give-up flags per tile: bit = part.
+    constexpr int kSplit = NF / 2;
+    auto exp_block = [&](int ni) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -595,98 +601,87 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
       }
       const float tot = psum[ni] + __shfl_xor(psum[ni], 32);
       if (half == 0) Pw[wm * FT + arow0 + 32 * ni + frow] = tot;
-    }
-    __syncthreads();
+    };
 #if FDNN_GEMM_DEBUG & 64
     long long tf[6];
-    tf[0] = __builtin_readcyclecounter();
+    tf[0] = tf[1] = tf[2] = tf[3] = __builtin_readcyclecounter();
 #endif
     float *gS = p.fuse_s + (static_cast<size_t>(nt) * MT + mt) * FT;
-    if (tid < FT / 4) {
-      v4f_t s4;
+    uint32_t *cnt = p.fuse_cnt + 4 * nt;  // all zero between launches
+    // frame row f of the tile belongs to block (f % (32 NF)) / 32 of its wave half
+    auto part_of_row = [&](int f) { return ((f % (32 * NF)) >> 5) < kSplit ? 0 : 1; };
+    auto publish = [&](int part) {
+      __syncthreads();  // the part's Pw entries are complete
+      if (tid < FT / 4 && part_of_row(4 * tid) == part) {
+        v4f_t s4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f = 4 * tid + q;
-        s4[q] = (Pw[f] + Pw[FT + f]) + (Pw[2 * FT + f] + Pw[3 * FT + f]);
-      }
-      store_wt(gS + 4 * tid, s4);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the S stores have left (inline-asm stores: nobody else waits for them)
-    __syncthreads();
-#if FDNN_GEMM_DEBUG & 64
-    tf[1] = __builtin_readcyclecounter();
-#endif
-    uint32_t *cnt = p.fuse_cnt + 2 * nt;  // [arrived, left]; both zero between launches
-    if (tid == 0) {
-      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int ok = (p.debug & 4096) && mt % 3 == 0 ? 0 : 1, spins = 0;  // FDNN_GEMM_DEBUG=4096 (tests): every third node tile "gives up"
-      while (ok && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < static_cast<uint32_t>(MT)) {
-        __builtin_amdgcn_s_sleep(16);
-        if (++spins > (1 << 15)) {  // tens of milliseconds (a legitimate wait is microseconds): something keeps this frame tile's other workgroups off the chip
-          ok = 0;
-          break;
+        for (int q = 0; q < 4; ++q) {
+          const int f = 4 * tid + q;
+          s4[q] = (Pw[f] + Pw[FT + f]) + (Pw[2 * FT + f] + Pw[3 * FT + f]);
         }
+        store_wt(gS + 4 * tid, s4);
       }
-      ok_s[0] = ok;
-    }
-    __syncthreads();
-    const bool ok = ok_s[0] != 0;
-#if FDNN_GEMM_DEBUG & 64
-    tf[2] = __builtin_readcyclecounter();
-#endif
-    if (ok) {
-      // all MT vectors of S, past the (non-coherent) L2: four 16-byte loads per lane in flight
-      const float *gall = p.fuse_s + static_cast<size_t>(nt) * MT * FT;
-      const int n4 = MT * FT / 4;
-      for (int i0 = tid; i0 < n4; i0 += 8 * Cfg::THREADS) {  // eight 16-byte loads per lane in flight: one round trip for MT = 32
-        int ix[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) ix[u] = min(i0 + u * Cfg::THREADS, n4 - 1);  // (clamped duplicates rewrite the same bytes)
-        v4f_t v0, v1, v2, v3, v4, v5, v6, v7;
-        asm volatile(
-            "global_load_dwordx4 %0, %8, off sc0 sc1\n\tglobal_load_dwordx4 %1, %9, off sc0 sc1\n\t"
-            "global_load_dwordx4 %2, %10, off sc0 sc1\n\tglobal_load_dwordx4 %3, %11, off sc0 sc1\n\t"
-            "global_load_dwordx4 %4, %12, off sc0 sc1\n\tglobal_load_dwordx4 %5, %13, off sc0 sc1\n\t"
-            "global_load_dwordx4 %6, %14, off sc0 sc1\n\tglobal_load_dwordx4 %7, %15, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-            : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
-            : "v"(gall + 4 * static_cast<size_t>(ix[0])), "v"(gall + 4 * static_cast<size_t>(ix[1])), "v"(gall + 4 * static_cast<size_t>(ix[2])),
-              "v"(gall + 4 * static_cast<size_t>(ix[3])), "v"(gall + 4 * static_cast<size_t>(ix[4])), "v"(gall + 4 * static_cast<size_t>(ix[5])),
-              "v"(gall + 4 * static_cast<size_t>(ix[6])), "v"(gall + 4 * static_cast<size_t>(ix[7]))
-            : "memory");
-        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[0]) = v0;
-        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[1]) = v1;
-        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[2]) = v2;
-        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[3]) = v3;
-        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[4]) = v4;
-        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[5]) = v5;
-        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[6]) = v6;
-        *reinterpret_cast<v4f_t *>(Sg + 4 * ix[7]) = v7;
-      }
-      for (int i = MT * FT + tid; i < L * FT; i += Cfg::THREADS) Sg[i] = 0.0f;  // zero padding: x + 0 = x
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the S stores have left (inline-asm stores: nobody else waits for them)
       __syncthreads();
-      if (tid < FT) {  // adjacent pairs, level by level (normalize_row's tree), one frame per thread, in place
-        for (int len = L >> 1; len >= 1; len >>= 1)
-          for (int i = 0; i < len; ++i) Sg[i * FT + tid] = Sg[2 * i * FT + tid] + Sg[(2 * i + 1) * FT + tid];
-        inv_s[tid] = 1.0f / Sg[tid];  // p_i = e_i * RN(1 / total), as normalize_row
+      if (tid == 0) __hip_atomic_fetch_add(cnt + part, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    uint32_t gave_up = 0;  // (meaningful in thread 0 only: ok_s carries the verdict to the others)
+    // wait for the part's MT arrivals, fetch its MT x frames sums past the (non-coherent) L2s, finish the tree per frame
+    auto collect = [&](int part) {
+      if (tid == 0) {
+        int ok = (p.debug & 4096) && mt % 3 == part ? 0 : 1, spins = 0;  // FDNN_GEMM_DEBUG=4096 (tests): some node tiles "give up" on one part
+        while (ok && __hip_atomic_load(cnt + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < static_cast<uint32_t>(MT)) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > (1 << 15)) {  // tens of milliseconds (a legitimate wait is microseconds): something keeps this frame tile's other workgroups off the chip
+            ok = 0;
+            break;
+          }
+        }
+        ok_s[0] = ok;
+        if (!ok) gave_up |= 1u << part;
       }
-    } else {
-      if (tid < FT) inv_s[tid] = 1.0f;
-      if (tid == 0) p.fuse_flag[static_cast<size_t>(nt) * MT + mt] = 1u;  // fuse_cleanup_kernel scales this tile
-    }
-    __syncthreads();
-    if (tid == 0) {  // the last workgroup to leave the frame tile resets its counters for the next launch
-      const uint32_t prev = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (prev == static_cast<uint32_t>(MT) - 1u) {
-        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-#if FDNN_GEMM_DEBUG & 64
-    tf[3] = __builtin_readcyclecounter();
-#endif
-    // phase 2: scale, transpose through the wave's LDS tile, 256-byte row segments out
+      __syncthreads();
+      const bool ok = ok_s[0] != 0;
+      const int lo = part == 0 ? 0 : kSplit, nb_part = part == 0 ? kSplit : NF - kSplit;  // 32-frame blocks of the part, per wave half
+      const int quads = WN * nb_part * 8;                                                 // 4-frame pieces of the part
+      if (ok) {
+        const float *gall = p.fuse_s + static_cast<size_t>(nt) * MT * FT;
+        const int items = MT * quads;
+        for (int i0 = tid; i0 < items; i0 += 4 * Cfg::THREADS) {  // four 16-byte loads per lane in flight
+          int off[4];
 #pragma unroll
-    for (int ni = 0; ni < NF; ++ni) {
+          for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * Cfg::THREADS, items - 1);  // (clamped duplicates rewrite the same bytes)
+            const int row = i / quads, j = i - row * quads, blk = j >> 3, f0q = (blk / nb_part) * (32 * NF) + 32 * (lo + blk % nb_part) + 4 * (j & 7);
+            off[u] = row * FT + f0q;
+          }
+          v4f_t v0, v1, v2, v3;
+          asm volatile(
+              "global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+              "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+              : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+              : "v"(gall + off[0]), "v"(gall + off[1]), "v"(gall + off[2]), "v"(gall + off[3])
+              : "memory");
+          *reinterpret_cast<v4f_t *>(Sg + off[0]) = v0;
+          *reinterpret_cast<v4f_t *>(Sg + off[1]) = v1;
+          *reinterpret_cast<v4f_t *>(Sg + off[2]) = v2;
+          *reinterpret_cast<v4f_t *>(Sg + off[3]) = v3;
+        }
+        for (int i = MT * FT + tid; i < L * FT; i += Cfg::THREADS)
+          if (part_of_row(i % FT) == part) Sg[i] = 0.0f;  // zero padding: x + 0 = x
+        __syncthreads();
+        if (tid < FT && part_of_row(tid) == part) {  // adjacent pairs, level by level (normalize_row's tree), one frame per thread, in place
+          for (int len = L >> 1; len >= 1; len >>= 1)
+            for (int i = 0; i < len; ++i) Sg[i * FT + tid] = Sg[2 * i * FT + tid] + Sg[(2 * i + 1) * FT + tid];
+          inv_s[tid] = 1.0f / Sg[tid];  // p_i = e_i * RN(1 / total), as normalize_row
+        }
+      } else if (tid < FT && part_of_row(tid) == part) {
+        inv_s[tid] = 1.0f;  // this part of the tile leaves unscaled: fuse_cleanup_kernel scales it
+      }
+      __syncthreads();
+    };
+    // phase 2 for one block: scale, transpose through the wave's LDS tile, 256-byte row segments out
+    auto scale_store = [&](int ni) {
       const float iv = inv_s[arow0 + 32 * ni + frow];
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -709,12 +704,46 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
         if (ff < p.n && ncol0 + col + 4 <= p.rows) store_wt(p.final + static_cast<size_t>(ff) * p.rows + ncol0 + col, v);
 #endif
       }
-    }
+    };
+#pragma unroll
+    for (int ni = 0; ni < kSplit; ++ni) exp_block(ni);
+    publish(0);
+#if FDNN_GEMM_DEBUG & 64
+    tf[1] = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+    for (int ni = kSplit; ni < NF; ++ni) exp_block(ni);
+    publish(1);
+#if FDNN_GEMM_DEBUG & 64
+    tf[2] = __builtin_readcyclecounter();
+#endif
+    collect(0);
+#if FDNN_GEMM_DEBUG & 64
+    tf[3] = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+    for (int ni = 0; ni < kSplit; ++ni) scale_store(ni);
+    collect(1);
 #if FDNN_GEMM_DEBUG & 64
     tf[4] = __builtin_readcyclecounter();
+#endif
+#pragma unroll
+    for (int ni = kSplit; ni < NF; ++ni) scale_store(ni);
+    if (tid == 0) {
+      if (gave_up) p.fuse_flag[static_cast<size_t>(nt) * MT + mt] = gave_up;  // fuse_cleanup_kernel scales those parts of this tile
+      // the last workgroup to leave the frame tile resets its counters for the next launch
+      const uint32_t prev = __hip_atomic_fetch_add(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev == static_cast<uint32_t>(MT) - 1u) {
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#if FDNN_GEMM_DEBUG & 64
+    tf[5] = __builtin_readcyclecounter();
     if (tid == 0 && (blockIdx.x % 149) == 0)
-      printf("FUSED %4d: prologue %lld first-stage %lld mainloop %lld | exp %lld publish %lld wait %lld gather+tree %lld scale+store %lld | total %lld\n", blockIdx.x,
-             ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], tf[0] - ts[3], tf[1] - tf[0], tf[2] - tf[1], tf[3] - tf[2], tf[4] - tf[3], tf[4] - ts[0]);
+      printf("FUSED %4d: prologue %lld first-stage %lld mainloop %lld | exp A + publish %lld exp B + publish %lld collect A %lld store A + collect B %lld store B %lld | total %lld\n",
+             blockIdx.x, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], tf[1] - ts[3], tf[2] - tf[1], tf[3] - tf[2], tf[4] - tf[3], tf[5] - tf[4], tf[5] - ts[0]);
 #endif
     return;
   }
@@ -989,22 +1018,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
 // Fused soft-max, the path nobody should ever see: a workgroup whose wait for its frame tile's other node tiles timed out
 // has stored exp(z) unscaled and raised its flag.  By the time this kernel runs every tile has published its row sums,
 // so the totals are complete: scale the flagged tile's block (one thread per frame), lower the flag.
-__global__ __launch_bounds__(64) void fuse_cleanup_kernel(QGemmParams p, int FT) {
+__global__ __launch_bounds__(64) void fuse_cleanup_kernel(QGemmParams p, int FT, int NF) {
   // one 64-thread workgroup per FRAME tile: normally 32 flag reads, one ballot, done (a workgroup per tile was 8192
-  // workgroups and 4 us of launch for nothing)
-  const int MT = p.rows_pad / 256, nt = blockIdx.x;
+  // workgroups and 4 us of launch for nothing).  A flag's bits name the parts of the two-part exchange the tile left
+  // unscaled (bit 0: the 32-frame blocks ni < NF / 2 of each wave half, bit 1: the others).
+  const int MT = p.rows_pad / 256, nt = blockIdx.x, split = NF / 2;
   int L = 1;
   while (L < MT) L <<= 1;
   for (int mt0 = 0; mt0 < MT; mt0 += 64) {
     const int mine = mt0 + static_cast<int>(threadIdx.x);
-    const bool flagged = mine < MT && p.fuse_flag[static_cast<size_t>(nt) * MT + mine] != 0u;
-    unsigned long long todo = __ballot(flagged);
+    const uint32_t myflag = mine < MT ? p.fuse_flag[static_cast<size_t>(nt) * MT + mine] : 0u;
+    unsigned long long todo = __ballot(myflag != 0u);
     while (todo) {
-      const int mt = mt0 + __ffsll(static_cast<long long>(todo)) - 1;
+      const int src = __ffsll(static_cast<long long>(todo)) - 1, mt = mt0 + src;
       todo &= todo - 1;
+      const uint32_t parts = __shfl(myflag, src);
       for (int f = threadIdx.x; f < FT; f += 64) {
-        const int frame = nt * FT + f;
-        if (frame >= p.n) continue;
+        const int frame = nt * FT + f, part = ((f % (32 * NF)) >> 5) < split ? 0 : 1;
+        if (frame >= p.n || !((parts >> part) & 1u)) continue;
         float x[64];  // MT <= 32 on this path (qgemm_fused_ok)
         for (int j = 0; j < 64; ++j) x[j] = j < MT ? p.fuse_s[(static_cast<size_t>(nt) * MT + j) * FT + f] : 0.0f;
         for (int len = L >> 1; len >= 1; len >>= 1)
@@ -1055,7 +1086,7 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     // fused soft-max: the node tiles of a frame tile are consecutive blocks; a second, near-empty launch scales whatever a
     // workgroup that gave up waiting left unscaled (normally nothing: every workgroup reads one flag and leaves)
     hipLaunchKernelGGL(p.mask ? k_fused_masked : k_fused, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
-    hipLaunchKernelGGL(fuse_cleanup_kernel, dim3(NT), dim3(64), 0, s, p, Cfg::FT);
+    hipLaunchKernelGGL(fuse_cleanup_kernel, dim3(NT), dim3(64), 0, s, p, Cfg::FT, NF);
   } else if (p.tap_acc)
     hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else if (OUTPUT && p.mask == nullptr && (p.rows & 31) == 0)
