@@ -48,6 +48,9 @@
 #ifndef FDNN_GEMM_DEBUG
 #define FDNN_GEMM_DEBUG 0
 #endif
+#ifndef FDNN_FUSE_PARTS
+#define FDNN_FUSE_PARTS 2  // parts of the fused soft-max's row-sum exchange (one per 32-frame block at most)
+#endif
 #ifndef FDNN_SMALL_STAGES
 #define FDNN_SMALL_STAGES 3  // ring depth of the 256-node x 32-frame tile (4: no change measured)
 #endif
@@ -557,12 +560,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
       fmw[ni] = (MASKED && ff < p.n && grp < p.mask_wpr) ? p.mask_bits[static_cast<size_t>(ff) * p.mask_wpr + grp] : 0ull;
     }
     // Round 4: the exchange in TWO PARTS.  A frame's row sum is complete as soon as its own 32-frame block has gone through
-    // phase 1, so the sums of the blocks ni < kSplit are published (and their arrival counted) before the remaining blocks'
+    // phase 1, so the sums of the first part's blocks are published (and their arrival counted) before the remaining blocks'
     // exp work; by the time a workgroup has finished phase 1 its siblings' first part has long been published, and while it
     // scales and stores the first part's blocks their second part arrives: of the wait for the slowest of the MT siblings
-    // only what exceeds that slack is left.  Same sums, same tree, same bits.  Counters per frame tile:
-    // {arrived part 0, arrived part 1, left, -}; give-up flags per tile: bit = part.
-    constexpr int kSplit = NF / 2;
+    // only what exceeds that slack is left.  Same sums, same tree, same bits.  Counters per frame tile: arrivals per part,
+    // leavers at [7]; give-up flags per tile: bit = part.  Measured, 10 000 x 8000: one part 229-234 us, two 220-222,
+    // three 228, five 248 (every part is two more barriers, an atomic and a gather).
+    constexpr int kParts = FDNN_FUSE_PARTS < NF ? FDNN_FUSE_PARTS : NF;  // block ni belongs to part ni * kParts / NF
+    auto part_lo = [](int part) { return (part * NF + kParts - 1) / kParts; };  // first block of a part (part_lo(kParts) = NF)
     auto exp_block = [&](int ni) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -607,9 +612,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     tf[0] = tf[1] = tf[2] = tf[3] = __builtin_readcyclecounter();
 #endif
     float *gS = p.fuse_s + (static_cast<size_t>(nt) * MT + mt) * FT;
-    uint32_t *cnt = p.fuse_cnt + 4 * nt;  // all zero between launches
+    uint32_t *cnt = p.fuse_cnt + 8 * nt;  // {arrived part 0 .. kParts - 1, ..., left at [7]}: all zero between launches
     // frame row f of the tile belongs to block (f % (32 NF)) / 32 of its wave half
-    auto part_of_row = [&](int f) { return ((f % (32 * NF)) >> 5) < kSplit ? 0 : 1; };
+    auto part_of_row = [&](int f) { return ((f % (32 * NF)) >> 5) * kParts / NF; };
     auto publish = [&](int part) {
       __syncthreads();  // the part's Pw entries are complete
       if (tid < FT / 4 && part_of_row(4 * tid) == part) {
@@ -629,7 +634,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     // wait for the part's MT arrivals, fetch its MT x frames sums past the (non-coherent) L2s, finish the tree per frame
     auto collect = [&](int part) {
       if (tid == 0) {
-        int ok = (p.debug & 4096) && mt % 3 == part ? 0 : 1, spins = 0;  // FDNN_GEMM_DEBUG=4096 (tests): some node tiles "give up" on one part
+        int ok = (p.debug & 4096) && mt % 3 == part % 3 ? 0 : 1, spins = 0;  // FDNN_GEMM_DEBUG=4096 (tests): some node tiles "give up" on one part
         while (ok && __hip_atomic_load(cnt + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < static_cast<uint32_t>(MT)) {
           __builtin_amdgcn_s_sleep(16);
           if (++spins > (1 << 15)) {  // tens of milliseconds (a legitimate wait is microseconds): something keeps this frame tile's other workgroups off the chip
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
       }
       __syncthreads();
       const bool ok = ok_s[0] != 0;
-      const int lo = part == 0 ? 0 : kSplit, nb_part = part == 0 ? kSplit : NF - kSplit;  // 32-frame blocks of the part, per wave half
+      const int lo = part_lo(part), nb_part = part_lo(part + 1) - lo;  // 32-frame blocks of the part, per wave half
       const int quads = WN * nb_part * 8;                                                 // 4-frame pieces of the part
       if (ok) {
         const float *gall = p.fuse_s + static_cast<size_t>(nt) * MT * FT;
@@ -706,44 +711,36 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
       }
     };
 #pragma unroll
-    for (int ni = 0; ni < kSplit; ++ni) exp_block(ni);
-    publish(0);
-#if FDNN_GEMM_DEBUG & 64
-    tf[1] = __builtin_readcyclecounter();
-#endif
+    for (int part = 0; part < kParts; ++part) {
 #pragma unroll
-    for (int ni = kSplit; ni < NF; ++ni) exp_block(ni);
-    publish(1);
+      for (int ni = 0; ni < NF; ++ni)
+        if (ni * kParts / NF == part) exp_block(ni);
+      publish(part);
+    }
 #if FDNN_GEMM_DEBUG & 64
     tf[2] = __builtin_readcyclecounter();
 #endif
-    collect(0);
-#if FDNN_GEMM_DEBUG & 64
-    tf[3] = __builtin_readcyclecounter();
-#endif
 #pragma unroll
-    for (int ni = 0; ni < kSplit; ++ni) scale_store(ni);
-    collect(1);
-#if FDNN_GEMM_DEBUG & 64
-    tf[4] = __builtin_readcyclecounter();
-#endif
+    for (int part = 0; part < kParts; ++part) {
+      collect(part);
 #pragma unroll
-    for (int ni = kSplit; ni < NF; ++ni) scale_store(ni);
+      for (int ni = 0; ni < NF; ++ni)
+        if (ni * kParts / NF == part) scale_store(ni);
+    }
     if (tid == 0) {
       if (gave_up) p.fuse_flag[static_cast<size_t>(nt) * MT + mt] = gave_up;  // fuse_cleanup_kernel scales those parts of this tile
       // the last workgroup to leave the frame tile resets its counters for the next launch
-      const uint32_t prev = __hip_atomic_fetch_add(cnt + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t prev = __hip_atomic_fetch_add(cnt + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (prev == static_cast<uint32_t>(MT) - 1u) {
-        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(cnt + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) __hip_atomic_store(cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
 #if FDNN_GEMM_DEBUG & 64
     tf[5] = __builtin_readcyclecounter();
     if (tid == 0 && (blockIdx.x % 149) == 0)
-      printf("FUSED %4d: prologue %lld first-stage %lld mainloop %lld | exp A + publish %lld exp B + publish %lld collect A %lld store A + collect B %lld store B %lld | total %lld\n",
-             blockIdx.x, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], tf[1] - ts[3], tf[2] - tf[1], tf[3] - tf[2], tf[4] - tf[3], tf[5] - tf[4], tf[5] - ts[0]);
+      printf("FUSED %4d: prologue %lld first-stage %lld mainloop %lld | exp + publish (all parts) %lld collect + scale + store %lld | total %lld\n", blockIdx.x,
+             ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], tf[2] - ts[3], tf[5] - tf[2], tf[5] - ts[0]);
 #endif
     return;
   }
@@ -1018,11 +1015,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
 // Fused soft-max, the path nobody should ever see: a workgroup whose wait for its frame tile's other node tiles timed out
 // has stored exp(z) unscaled and raised its flag.  By the time this kernel runs every tile has published its row sums,
 // so the totals are complete: scale the flagged tile's block (one thread per frame), lower the flag.
-__global__ __launch_bounds__(64) void fuse_cleanup_kernel(QGemmParams p, int FT, int NF) {
+__global__ __launch_bounds__(64) void fuse_cleanup_kernel(QGemmParams p, int FT, int NF, int parts_n) {
   // one 64-thread workgroup per FRAME tile: normally 32 flag reads, one ballot, done (a workgroup per tile was 8192
   // workgroups and 4 us of launch for nothing).  A flag's bits name the parts of the two-part exchange the tile left
-  // unscaled (bit 0: the 32-frame blocks ni < NF / 2 of each wave half, bit 1: the others).
-  const int MT = p.rows_pad / 256, nt = blockIdx.x, split = NF / 2;
+  // unscaled (block ni of a wave half belongs to part ni * parts / NF).
+  const int MT = p.rows_pad / 256, nt = blockIdx.x;
   int L = 1;
   while (L < MT) L <<= 1;
   for (int mt0 = 0; mt0 < MT; mt0 += 64) {
@@ -1034,7 +1031,7 @@ __global__ __launch_bounds__(64) void fuse_cleanup_kernel(QGemmParams p, int FT,
       todo &= todo - 1;
       const uint32_t parts = __shfl(myflag, src);
       for (int f = threadIdx.x; f < FT; f += 64) {
-        const int frame = nt * FT + f, part = ((f % (32 * NF)) >> 5) < split ? 0 : 1;
+        const int frame = nt * FT + f, part = ((f % (32 * NF)) >> 5) * parts_n / NF;
         if (frame >= p.n || !((parts >> part) & 1u)) continue;
         float x[64];  // MT <= 32 on this path (qgemm_fused_ok)
         for (int j = 0; j < 64; ++j) x[j] = j < MT ? p.fuse_s[(static_cast<size_t>(nt) * MT + j) * FT + f] : 0.0f;
@@ -1086,7 +1083,7 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     // fused soft-max: the node tiles of a frame tile are consecutive blocks; a second, near-empty launch scales whatever a
     // workgroup that gave up waiting left unscaled (normally nothing: every workgroup reads one flag and leaves)
     hipLaunchKernelGGL(p.mask ? k_fused_masked : k_fused, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
-    hipLaunchKernelGGL(fuse_cleanup_kernel, dim3(NT), dim3(64), 0, s, p, Cfg::FT, NF);
+    hipLaunchKernelGGL(fuse_cleanup_kernel, dim3(NT), dim3(64), 0, s, p, Cfg::FT, NF, FDNN_FUSE_PARTS < NF ? FDNN_FUSE_PARTS : NF);
   } else if (p.tap_acc)
     hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else if (OUTPUT && p.mask == nullptr && (p.rows & 31) == 0)

@@ -216,9 +216,9 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
   {  // fused soft-max (large dense batches): row sums per 256-node tile, counters and flags per tile (kept zero between launches)
     const size_t mt = size_t(max_rows_pad / 256), tiles = npt / 128 + 2;  // frame tiles of 128 frames and up
     alloc(reinterpret_cast<void **>(&c->d_fuse_s), sizeof(float) * npt * mt);
-    alloc(reinterpret_cast<void **>(&c->d_fuse_cnt), sizeof(uint32_t) * 4 * tiles);
+    alloc(reinterpret_cast<void **>(&c->d_fuse_cnt), sizeof(uint32_t) * 8 * tiles);
     alloc(reinterpret_cast<void **>(&c->d_fuse_flag), sizeof(uint32_t) * tiles * mt);
-    if (e == hipSuccess) e = hipMemset(c->d_fuse_cnt, 0, sizeof(uint32_t) * 4 * tiles);
+    if (e == hipSuccess) e = hipMemset(c->d_fuse_cnt, 0, sizeof(uint32_t) * 8 * tiles);
     if (e == hipSuccess) e = hipMemset(c->d_fuse_flag, 0, sizeof(uint32_t) * tiles * mt);
   }
   if (e == hipSuccess && !lean)  // (at least one padded row of slack)
