@@ -738,7 +738,7 @@ def main() -> None:
         fused_out = not prof["normalize"]["launches"]
         add("output_gemm", "qgemm_kernel<output> (int8 MFMA, 8000x2048 layer + dequant/bias/exp epilogue" +
             (" + FUSED soft-max: row sums exchanged between the 256-node tiles of a frame tile, probabilities written directly, "
-             "32 KB per frame out; includes the near-empty fuse_cleanup launch)" if fused_out else ", 32 KB of exp(z) per frame out)"),
+             "32 KB per frame out)" if fused_out else ", 32 KB of exp(z) per frame out)"),
             "mfma", 2.0 * 2048 * O * n, INT8_PEAK_TOPS, "TOP/s", 1e12, 2048 * O + n * 2048 + 4 * n * O, "qgemm_kernel output")
         add("normalize", "normalize_kernel (soft-max scale: read + write [n][8000] fp32)", "hbm", 2.0 * O * 4 * n, HBM_PEAK_GBS,
             "GB/s", 1e9, 2 * O * 4 * n, "normalize_kernel")

@@ -539,7 +539,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     // phase 2 multiplies its e by RN(1 / total) on the way out.  Placement-independent (sc0 sc1 stores and loads on
     // both sides, one relaxed agent-scope counter); progress: workgroups are dispatched in block order, so the oldest
     // unfinished frame tile always has all its MT workgroups resident.  Every spin is bounded: a workgroup that gives
-    // up stores exp(z) unscaled and flags its tile for fuse_cleanup_kernel.
+    // up stores exp(z) unscaled and flags its tile; the frame tile's last workgroup scales it.
     constexpr int kOS = 64 + 4;
     float *wtile = reinterpret_cast<float *>(smem + 8192) + wave * (32 * kOS);
     const int ncol0 = m0 + 64 * wm;
@@ -631,7 +631,42 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
       if (tid == 0) __hip_atomic_fetch_add(cnt + part, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     uint32_t gave_up = 0;  // (meaningful in thread 0 only: ok_s carries the verdict to the others)
-    // wait for the part's MT arrivals, fetch its MT x frames sums past the (non-coherent) L2s, finish the tree per frame
+    // a part's MT x frames sums, fetched past the (non-coherent) L2s, the tree per frame, inv_s = RN(1 / total)
+    auto totals = [&](int part) {
+      const int lo = part_lo(part), nb_part = part_lo(part + 1) - lo;  // 32-frame blocks of the part, per wave half
+      const int quads = WN * nb_part * 8;                              // 4-frame pieces of the part
+      const float *gall = p.fuse_s + static_cast<size_t>(nt) * MT * FT;
+      const int items = MT * quads;
+      for (int i0 = tid; i0 < items; i0 += 4 * Cfg::THREADS) {  // four 16-byte loads per lane in flight
+        int off[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = min(i0 + u * Cfg::THREADS, items - 1);  // (clamped duplicates rewrite the same bytes)
+          const int row = i / quads, j = i - row * quads, blk = j >> 3, f0q = (blk / nb_part) * (32 * NF) + 32 * (lo + blk % nb_part) + 4 * (j & 7);
+          off[u] = row * FT + f0q;
+        }
+        v4f_t v0, v1, v2, v3;
+        asm volatile(
+            "global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+            "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+            : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+            : "v"(gall + off[0]), "v"(gall + off[1]), "v"(gall + off[2]), "v"(gall + off[3])
+            : "memory");
+        *reinterpret_cast<v4f_t *>(Sg + off[0]) = v0;
+        *reinterpret_cast<v4f_t *>(Sg + off[1]) = v1;
+        *reinterpret_cast<v4f_t *>(Sg + off[2]) = v2;
+        *reinterpret_cast<v4f_t *>(Sg + off[3]) = v3;
+      }
+      for (int i = MT * FT + tid; i < L * FT; i += Cfg::THREADS)
+        if (part_of_row(i % FT) == part) Sg[i] = 0.0f;  // zero padding: x + 0 = x
+      __syncthreads();
+      if (tid < FT && part_of_row(tid) == part) {  // adjacent pairs, level by level (normalize_row's tree), one frame per thread, in place
+        for (int len = L >> 1; len >= 1; len >>= 1)
+          for (int i = 0; i < len; ++i) Sg[i * FT + tid] = Sg[2 * i * FT + tid] + Sg[(2 * i + 1) * FT + tid];
+        inv_s[tid] = 1.0f / Sg[tid];  // p_i = e_i * RN(1 / total), as normalize_row
+      }
+    };
+    // wait for the part's MT arrivals, then its totals
     auto collect = [&](int part) {
       if (tid == 0) {
         int ok = (p.debug & 4096) && mt % 3 == part % 3 ? 0 : 1, spins = 0;  // FDNN_GEMM_DEBUG=4096 (tests): some node tiles "give up" on one part
@@ -646,42 +681,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
         if (!ok) gave_up |= 1u << part;
       }
       __syncthreads();
-      const bool ok = ok_s[0] != 0;
-      const int lo = part_lo(part), nb_part = part_lo(part + 1) - lo;  // 32-frame blocks of the part, per wave half
-      const int quads = WN * nb_part * 8;                                                 // 4-frame pieces of the part
-      if (ok) {
-        const float *gall = p.fuse_s + static_cast<size_t>(nt) * MT * FT;
-        const int items = MT * quads;
-        for (int i0 = tid; i0 < items; i0 += 4 * Cfg::THREADS) {  // four 16-byte loads per lane in flight
-          int off[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int i = min(i0 + u * Cfg::THREADS, items - 1);  // (clamped duplicates rewrite the same bytes)
-            const int row = i / quads, j = i - row * quads, blk = j >> 3, f0q = (blk / nb_part) * (32 * NF) + 32 * (lo + blk % nb_part) + 4 * (j & 7);
-            off[u] = row * FT + f0q;
-          }
-          v4f_t v0, v1, v2, v3;
-          asm volatile(
-              "global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
-              "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-              : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
-              : "v"(gall + off[0]), "v"(gall + off[1]), "v"(gall + off[2]), "v"(gall + off[3])
-              : "memory");
-          *reinterpret_cast<v4f_t *>(Sg + off[0]) = v0;
-          *reinterpret_cast<v4f_t *>(Sg + off[1]) = v1;
-          *reinterpret_cast<v4f_t *>(Sg + off[2]) = v2;
-          *reinterpret_cast<v4f_t *>(Sg + off[3]) = v3;
-        }
-        for (int i = MT * FT + tid; i < L * FT; i += Cfg::THREADS)
-          if (part_of_row(i % FT) == part) Sg[i] = 0.0f;  // zero padding: x + 0 = x
-        __syncthreads();
-        if (tid < FT && part_of_row(tid) == part) {  // adjacent pairs, level by level (normalize_row's tree), one frame per thread, in place
-          for (int len = L >> 1; len >= 1; len >>= 1)
-            for (int i = 0; i < len; ++i) Sg[i * FT + tid] = Sg[2 * i * FT + tid] + Sg[(2 * i + 1) * FT + tid];
-          inv_s[tid] = 1.0f / Sg[tid];  // p_i = e_i * RN(1 / total), as normalize_row
-        }
+      if (ok_s[0] != 0) {
+        totals(part);
       } else if (tid < FT && part_of_row(tid) == part) {
-        inv_s[tid] = 1.0f;  // this part of the tile leaves unscaled: fuse_cleanup_kernel scales it
+        inv_s[tid] = 1.0f;  // this part of the tile leaves unscaled; the frame tile's last workgroup scales it (below)
       }
       __syncthreads();
     };
@@ -727,11 +730,56 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
       for (int ni = 0; ni < NF; ++ni)
         if (ni * kParts / NF == part) scale_store(ni);
     }
+    // ---- leaving.  A workgroup that gave up on a part has stored that part's block unscaled and raises a flag (bit = part); the
+    // LAST workgroup to leave the frame tile -- every sum has been published by then -- scales such blocks and lowers the
+    // flags: nothing is left for a second launch (rounds 3's fuse_cleanup_kernel: 4 us per step for, normally, nothing).
+    if (tid == 0) ok_s[1] = static_cast<int>(gave_up);
+    __syncthreads();
+    if (ok_s[1] != 0) {  // (uniform, rare) my unscaled stores must have reached memory before the flag can be seen
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     if (tid == 0) {
-      if (gave_up) p.fuse_flag[static_cast<size_t>(nt) * MT + mt] = gave_up;  // fuse_cleanup_kernel scales those parts of this tile
-      // the last workgroup to leave the frame tile resets its counters for the next launch
+      if (gave_up) {
+        __hip_atomic_store(p.fuse_flag + static_cast<size_t>(nt) * MT + mt, gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      }
       const uint32_t prev = __hip_atomic_fetch_add(cnt + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (prev == static_cast<uint32_t>(MT) - 1u) {
+      ok_s[2] = prev == static_cast<uint32_t>(MT) - 1u ? 1 : 0;
+    }
+    __syncthreads();
+    if (ok_s[2] != 0) {  // the last workgroup of the frame tile
+      uint32_t *fl_s = reinterpret_cast<uint32_t *>(Pw);  // [MT] (Pw is dead)
+      if (tid < MT) fl_s[tid] = __hip_atomic_load(p.fuse_flag + static_cast<size_t>(nt) * MT + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      uint32_t any = 0;
+      for (int j = 0; j < MT; ++j) any |= fl_s[j];
+      if (any) {  // (uniform) the path nobody should ever see
+        for (int part = 0; part < kParts; ++part) {
+          if (!((any >> part) & 1u)) continue;
+          __syncthreads();
+          totals(part);  // inv_s of the part's frames
+          __syncthreads();
+          for (int j = 0; j < MT; ++j) {
+            if (!((fl_s[j] >> part) & 1u)) continue;
+            // tile j's 256 columns of the part's frames: 64 four-column pieces per frame
+            for (int it = tid; it < FT * 64; it += Cfg::THREADS) {
+              const int f = it >> 6, c4 = j * 256 + 4 * (it & 63), frame = nt * FT + f;
+              if (part_of_row(f) != part || frame >= p.n || c4 + 4 > p.rows) continue;  // (rows % 32 == 0 on this path)
+              float *at = p.final + static_cast<size_t>(frame) * p.rows + c4;
+              v4f_t v;
+              asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(at) : "memory");
+              const float iv = inv_s[f];
+              store_wt(at, v4f_t{v.x * iv, v.y * iv, v.z * iv, v.w * iv});
+            }
+          }
+        }
+        if (tid < MT && fl_s[tid] != 0u) {
+          __hip_atomic_store(p.fuse_flag + static_cast<size_t>(nt) * MT + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (p.fuse_giveups) atomicAdd(p.fuse_giveups, 1ull);  // observable: fdnn_model_fuse_giveups
+        }
+      }
+      if (tid == 0) {  // the counters are ready for the next launch
 #pragma unroll
         for (int i = 0; i < 8; ++i) __hip_atomic_store(cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1012,43 +1060,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-// Fused soft-max, the path nobody should ever see: a workgroup whose wait for its frame tile's other node tiles timed out
-// has stored exp(z) unscaled and raised its flag.  By the time this kernel runs every tile has published its row sums,
-// so the totals are complete: scale the flagged tile's block (one thread per frame), lower the flag.
-__global__ __launch_bounds__(64) void fuse_cleanup_kernel(QGemmParams p, int FT, int NF, int parts_n) {
-  // one 64-thread workgroup per FRAME tile: normally 32 flag reads, one ballot, done (a workgroup per tile was 8192
-  // workgroups and 4 us of launch for nothing).  A flag's bits name the parts of the two-part exchange the tile left
-  // unscaled (block ni of a wave half belongs to part ni * parts / NF).
-  const int MT = p.rows_pad / 256, nt = blockIdx.x;
-  int L = 1;
-  while (L < MT) L <<= 1;
-  for (int mt0 = 0; mt0 < MT; mt0 += 64) {
-    const int mine = mt0 + static_cast<int>(threadIdx.x);
-    const uint32_t myflag = mine < MT ? p.fuse_flag[static_cast<size_t>(nt) * MT + mine] : 0u;
-    unsigned long long todo = __ballot(myflag != 0u);
-    while (todo) {
-      const int src = __ffsll(static_cast<long long>(todo)) - 1, mt = mt0 + src;
-      todo &= todo - 1;
-      const uint32_t parts = __shfl(myflag, src);
-      for (int f = threadIdx.x; f < FT; f += 64) {
-        const int frame = nt * FT + f, part = ((f % (32 * NF)) >> 5) * parts_n / NF;
-        if (frame >= p.n || !((parts >> part) & 1u)) continue;
-        float x[64];  // MT <= 32 on this path (qgemm_fused_ok)
-        for (int j = 0; j < 64; ++j) x[j] = j < MT ? p.fuse_s[(static_cast<size_t>(nt) * MT + j) * FT + f] : 0.0f;
-        for (int len = L >> 1; len >= 1; len >>= 1)
-          for (int i = 0; i < len; ++i) x[i] = x[2 * i] + x[2 * i + 1];
-        const float inv = 1.0f / x[0];
-        float *row = p.final + static_cast<size_t>(frame) * p.rows;
-        for (int c = mt * 256; c < min(p.rows, mt * 256 + 256); ++c) row[c] = row[c] * inv;
-      }
-      if (threadIdx.x == 0) {
-        p.fuse_flag[static_cast<size_t>(nt) * MT + mt] = 0u;
-        if (p.fuse_giveups) atomicAdd(p.fuse_giveups, 1ull);  // observable: fdnn_model_fuse_giveups
-      }
-    }
-  }
-}
-
 template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool FAST = true, int WM = 4>
 void launch_cfg(const QGemmParams &p, hipStream_t s) {
   using Cfg = GemmCfg<NF, WN, BK, STAGES, WM>;
@@ -1080,10 +1091,9 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
   if (kCanFuse && p.fuse_s != nullptr) {
-    // fused soft-max: the node tiles of a frame tile are consecutive blocks; a second, near-empty launch scales whatever a
-    // workgroup that gave up waiting left unscaled (normally nothing: every workgroup reads one flag and leaves)
+    // fused soft-max: the node tiles of a frame tile are consecutive blocks (what a workgroup that gave up waiting left
+    // unscaled is scaled by its frame tile's last workgroup: one launch)
     hipLaunchKernelGGL(p.mask ? k_fused_masked : k_fused, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
-    hipLaunchKernelGGL(fuse_cleanup_kernel, dim3(NT), dim3(64), 0, s, p, Cfg::FT, NF, FDNN_FUSE_PARTS < NF ? FDNN_FUSE_PARTS : NF);
   } else if (p.tap_acc)
     hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else if (OUTPUT && p.mask == nullptr && (p.rows & 31) == 0)

@@ -99,12 +99,12 @@ struct QGemmParams {
   int mask_wpr;               // production instances read one 64-bit word per frame row and 64-node group instead of 64 bytes
   // fused soft-max (large-batch dense output instance): where the probabilities go, the per-tile row sums S
   // [n_pad / frame_tile][rows_pad / 256][frame_tile], the per-frame-tile {arrived, left} counters (zero between launches)
-  // and the per-tile "gave up waiting" flags for fuse_cleanup_kernel; all null = the unfused path
+  // and the per-tile "gave up waiting" flags (the frame tile's last workgroup scales such blocks); all null = the unfused path
   float *final;
   float *fuse_s;
   uint32_t *fuse_cnt;
   uint32_t *fuse_flag;
-  unsigned long long *fuse_giveups;  // per model: tiles fuse_cleanup_kernel had to scale (a workgroup gave up waiting); null = not counted
+  unsigned long long *fuse_giveups;  // per model: tiles that had to be scaled after the fact (a workgroup gave up waiting); null = not counted
   // accumulator probe of the PRODUCTION output instances (parity tests only; null otherwise): the int32 accumulators of
   // every probe_stride-th frame, [ceil(n / probe_stride)][rows] -- a wave-uniform branch in front of the epilogue
   int32_t *acc_probe;

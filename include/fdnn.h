@@ -267,7 +267,7 @@ FDNN_API int fdnn_debug_layer0(fdnn_model *m, const float *x, int n, uint8_t *u8
 /* Fused soft-max health counter.  Large dense / batched-lazy calls scale their soft-max inside the output kernel: the
  * node tiles of a frame tile exchange row sums and wait for one another (bounded).  Within a process the library chains
  * those launches per device, so the wait is microseconds; a workgroup whose wait nevertheless timed out (another PROCESS
- * on the same GPU, see INTEGRATION.md: FDNN_FUSE_NORM=0) leaves its tile to a clean-up kernel -- same bits, tens of
+ * on the same GPU, see INTEGRATION.md: FDNN_FUSE_NORM=0) leaves its block to the frame tile's last workgroup -- same bits, tens of
  * milliseconds late.  *tiles = how many tiles that has happened to on this model since load (0 in a healthy setup).
  * SoftMax::apply, src/cpp/dnn.cc:534-544, is what is being computed. */
 FDNN_API int fdnn_model_fuse_giveups(fdnn_model *m, unsigned long long *tiles);

@@ -335,7 +335,7 @@ def test_fused_softmax_equals_the_scale_pass_and_its_give_up_path(net_model_path
     """Large dense batches scale the soft-max inside the output kernel (fused: exp(z) stays in registers, the 256-node
     tiles of a frame tile exchange row sums through memory).  Same bits as the unfused kernel + normalize pass
     (FDNN_FUSE_NORM=0), and the same bits again when every third node tile pretends its wait timed out
-    (FDNN_GEMM_DEBUG=4096): those tiles store exp(z) unscaled and fuse_cleanup_kernel finishes them."""
+    (FDNN_GEMM_DEBUG=4096): those tiles store that part of exp(z) unscaled and their frame tile's last workgroup finishes them."""
     import subprocess, sys
 
     code = f"""
