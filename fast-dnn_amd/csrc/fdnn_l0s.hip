@@ -54,13 +54,13 @@ namespace fdnn {
 namespace {
 
 #ifndef FDNN_L0S_DEBUG
-#define FDNN_L0S_DEBUG 0  // kernel-ablation timing builds only (tools/build_variant.sh): 1 no sampling, 2 no lower-order MFMAs, 4 no screening arithmetic in the epilogue, 8 no staging in the loop
+#define FDNN_L0S_DEBUG 0  // kernel-ablation timing builds only (tools/build_variant.sh): 1 no sampling, 2 no lower-order MFMAs, 4 no screening arithmetic in the epilogue, 8 no staging in the loop, 16 no barrier in the loop, 32 no fragment reads in the loop
 #endif
 constexpr float kU = 5.9604645e-8f;  // 2^-24
 constexpr int kSplitW = 32;          // steps between samples at most (one MFMA = 32 k)
 
 // same workgroup -> tile map as the other layer-0 kernels (fdnn_l0.hip): all node tiles of a frame tile on one XCD
-__device__ __forceinline__ bool split_tile_of_block(int node_tiles, int frame_tiles, int &bx, int &by) {
+[[maybe_unused]] __device__ __forceinline__ bool split_tile_of_block(int node_tiles, int frame_tiles, int &bx, int &by) {
   const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
   bx = slot % node_tiles;
   by = xcd + 8 * (slot / node_tiles);
