@@ -1024,41 +1024,56 @@ __device__ __forceinline__ float quad_bcast(float v) {
 #ifndef FDNN_L0_FIX_DEPTH
 #define FDNN_L0_FIX_DEPTH 3  // operand quads per lane in flight per round of the exact recomputation
 #endif
-// One listed output, four lanes = four chains (lane c is chain c; all four lanes of a quad must call this together).
-__device__ __forceinline__ void fix_one_output(const L0Params &p, const float *sh_s, const float *sc_s, int f, int node, bool live, int c, int quads) {
+// One listed output, LPO lanes (all of them must call this together): lane c fetches the quads of k-steps LPO i + c and keeps
+// chain c & 3 (LPO = 8: lanes 4..7 repeat chains 0..3, so that every quad of lanes ends with all four chain sums).
+template <int NB = FDNN_L0_FIX_DEPTH, int LPO = 4>
+__device__ __forceinline__ void fix_one_output(const L0Params &p, const float *sh_s, const float *sc_s, float *tr_w, int f, int node, bool live, int c, int quads) {
+  static_assert(LPO == 4 || LPO == 8, "lanes per output");
   typedef float v4f __attribute__((ext_vector_type(4)));
   const float *xr = p.x + static_cast<size_t>(live ? f : 0) * p.D, *wr = p.w + static_cast<size_t>(live ? node : 0) * p.D;
   float acc = 0.0f;
-  // 4 NB k-steps per round: the NB quads per lane (and operand) are all requested before the first is used -- the walk is
-  // a chain of L2 round trips, one per round (NB = 3: nine of them for D = 432)
-  constexpr int NB = FDNN_L0_FIX_DEPTH;
-  for (int q0 = 0; q0 < quads; q0 += 4 * NB) {
+  // LPO NB k-steps per round: the NB quads per lane (and operand) are all requested before the first is used -- the walk
+  // is a chain of L2 round trips, one per round (LPO = 4, NB = 3: nine of them for D = 432).
+  // Chain e needs element e of EVERY step's quad: the owner of a quad forms its four products (multiply rounds on its
+  // own, -ffp-contract=off), and the block of products of LPO consecutive steps changes hands through the wave's 1 KiB of
+  // LDS per b -- four conflict-free dword writes (element e of lane l to row e, slot l), then 16-byte reads of row c & 3,
+  // slots of the output's lanes = its steps in order.  Sixteen DPP broadcasts and twelve selects per four steps before:
+  // the chain was vector-instruction bound, not L2 bound.
+  const int lane = threadIdx.x & 63, l0 = lane & ~(LPO - 1);
+  for (int q0 = 0; q0 < quads; q0 += LPO * NB) {
     v4f xq[NB], wq[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const int q = min(q0 + 4 * b + c, quads - 1);  // (a clamped quad is never consumed: its step is skipped below)
+      const int q = min(q0 + LPO * b + c, quads - 1);  // (a clamped quad is never consumed: its step is skipped below)
       xq[b] = *reinterpret_cast<const v4f *>(xr + 4 * q);
       wq[b] = *reinterpret_cast<const v4f *>(wr + 4 * q);
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      const int q = min(q0 + 4 * b + c, quads - 1);
+      const int q = min(q0 + LPO * b + c, quads - 1);
       xq[b] = (xq[b] + *reinterpret_cast<const v4f *>(sh_s + 4 * q)) * *reinterpret_cast<const v4f *>(sc_s + 4 * q);  // add, then multiply
+      const v4f pr = xq[b] * wq[b];  // product and sum round separately (dnn.cc:233-238)
+      float *t = tr_w + b * 256;
+      t[0 * 64 + lane] = pr.x;
+      t[1 * 64 + lane] = pr.y;
+      t[2 * 64 + lane] = pr.z;
+      t[3 * 64 + lane] = pr.w;
     }
-#define FDNN_FIX_STEP(B, S)                                                                                                   \
-  if (q0 + 4 * B + S < quads) {                                                                                               \
-    const float x0 = quad_bcast<S>(xq[B].x), x1 = quad_bcast<S>(xq[B].y), x2 = quad_bcast<S>(xq[B].z), x3 = quad_bcast<S>(xq[B].w); \
-    const float w0 = quad_bcast<S>(wq[B].x), w1 = quad_bcast<S>(wq[B].y), w2 = quad_bcast<S>(wq[B].z), w3 = quad_bcast<S>(wq[B].w); \
-    const float xs = c == 0 ? x0 : c == 1 ? x1 : c == 2 ? x2 : x3;                                                            \
-    const float wv = c == 0 ? w0 : c == 1 ? w1 : c == 2 ? w2 : w3;                                                            \
-    const float pr = xs * wv; /* this file is compiled -ffp-contract=off: product and sum round separately */                \
-    acc = acc + pr;           /* (dnn.cc:233-238) */                                                                          \
-  }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (compiler ordering only: the exchange is between lanes of one wave,
+    __builtin_amdgcn_wave_barrier();                        //  whose LDS operations complete in order)
 #pragma unroll
-    for (int B = 0; B < NB; ++B) {
-      FDNN_FIX_STEP(B, 0) FDNN_FIX_STEP(B, 1) FDNN_FIX_STEP(B, 2) FDNN_FIX_STEP(B, 3)
-    }
-#undef FDNN_FIX_STEP
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int h = 0; h < LPO / 4; ++h) {
+        const v4f r = *reinterpret_cast<const v4f *>(tr_w + b * 256 + (c & 3) * 64 + l0 + 4 * h);
+        const int st = q0 + LPO * b + 4 * h;
+        if (st + 0 < quads) acc = acc + r.x;
+        if (st + 1 < quads) acc = acc + r.y;
+        if (st + 2 < quads) acc = acc + r.z;
+        if (st + 3 < quads) acc = acc + r.w;
+      }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   const float c0 = quad_bcast<0>(acc), c1 = quad_bcast<1>(acc), c2 = quad_bcast<2>(acc), c3 = quad_bcast<3>(acc);
   if (live && c == 0) {
@@ -1074,7 +1089,6 @@ __device__ __forceinline__ void fix_one_output(const L0Params &p, const float *s
 constexpr int kFixThreads = FDNN_L0_FIX_THREADS;
 __global__ __launch_bounds__(kFixThreads) void l0_fix_kernel(L0Params p, int TF) {  // TF: the screening kernel's frame tile (128 or 64)
   constexpr int TN = 128;
-  typedef float v4f __attribute__((ext_vector_type(4)));
   const int node_tiles = (p.H + TN - 1) / TN;
   const int tile_id = blockIdx.x, by = tile_id / node_tiles, bx = tile_id % node_tiles;
   const uint32_t count = p.scr_count[tile_id];
@@ -1086,17 +1100,18 @@ __global__ __launch_bounds__(kFixThreads) void l0_fix_kernel(L0Params p, int TF)
   const int quads = p.D / 4;  // D is a multiple of 4
   extern __shared__ __attribute__((aligned(16))) float fix_smem[];  // shift[D], scale[D]
   float *sh_s = fix_smem, *sc_s = fix_smem + p.D;
+  float *tr_w = fix_smem + 2 * p.D + (tid >> 6) * (FDNN_L0_FIX_DEPTH * 256);  // this wave's product blocks (fix_one_output)
   for (int k = tid; k < p.D; k += kFixThreads) {
     sh_s[k] = p.shift[k];
     sc_s[k] = p.scale[k];
   }
   __syncthreads();
-  for (int base = 0; base < total; base += kFixThreads / 4) {  // (uniform trip count: the quad broadcasts need all four lanes present)
+  for (int base = 0; base < total; base += kFixThreads / 4) {  // (uniform trip count: all four lanes of an output must be present)
     const int o = base + (tid >> 2);
     const bool valid = o < total;
     const int local = valid ? (all ? o : p.scr_list[static_cast<size_t>(tile_id) * kL0ScreenCap + o]) : 0;
     const int f = f0 + local / TN, node = n0 + local % TN;
-    fix_one_output(p, sh_s, sc_s, f, node, valid && f < p.n && node < p.H, c, quads);
+    fix_one_output(p, sh_s, sc_s, tr_w, f, node, valid && f < p.n && node < p.H, c, quads);
   }
   __syncthreads();  // every thread has read the count and its entries
   if (tid == 0) {
@@ -1110,25 +1125,28 @@ __global__ __launch_bounds__(kFixThreads) void l0_fix_kernel(L0Params p, int TF)
 // atomic per tile), recomputed 128 per workgroup pass.  With a workgroup per tile every workgroup ran one pass for its
 // ~70 outputs -- 1280 latency-bound passes, 2.5 rounds of them on the chip; the same outputs are 570 full passes, all
 // resident at once.  A tile whose own count overflowed the per-tile list (> 25 % flagged) is still recomputed whole.
-__global__ __launch_bounds__(kFixThreads) void l0_fix_list_kernel(L0Params p, int tiles) {
+template <int NB, int THREADS, int LPO>
+__global__ __launch_bounds__(THREADS) void l0_fix_list_kernel(L0Params p, int tiles) {
   constexpr int TN = 128, TF = 128;
-  const int tid = threadIdx.x, c = tid & 3;
+  constexpr int kFixThreads = THREADS;  // (shadows the per-tile kernel's constant)
+  const int tid = threadIdx.x, c = tid & (LPO - 1);
   const int quads = p.D / 4;
   extern __shared__ __attribute__((aligned(16))) float fix_smem[];  // shift[D], scale[D]
   float *sh_s = fix_smem, *sc_s = fix_smem + p.D;
+  float *tr_w = fix_smem + 2 * p.D + (tid >> 6) * (NB * 256);  // this wave's product blocks (fix_one_output)
   const uint32_t total = min(p.glist_count[0], static_cast<uint32_t>(p.glist_cap));
   const bool any_overflow = p.glist_count[1] != 0u;  // some tile kept its outputs to itself (scr_count / whole-tile path)
-  if (static_cast<uint32_t>(blockIdx.x) * (kFixThreads / 4) >= total && !any_overflow) return;
+  if (static_cast<uint32_t>(blockIdx.x) * (kFixThreads / LPO) >= total && !any_overflow) return;
   for (int k = tid; k < p.D; k += kFixThreads) {
     sh_s[k] = p.shift[k];
     sc_s[k] = p.scale[k];
   }
   __syncthreads();
-  for (uint32_t base = blockIdx.x * (kFixThreads / 4); base < total; base += gridDim.x * (kFixThreads / 4)) {
-    const uint32_t o = base + (tid >> 2);
+  for (uint32_t base = blockIdx.x * (kFixThreads / LPO); base < total; base += gridDim.x * (kFixThreads / LPO)) {
+    const uint32_t o = base + (tid / LPO);
     const bool valid = o < total;
     const uint2 ent = valid ? p.glist[o] : make_uint2(0u, 0u);
-    fix_one_output(p, sh_s, sc_s, static_cast<int>(ent.x), static_cast<int>(ent.y), valid && static_cast<int>(ent.x) < p.n && static_cast<int>(ent.y) < p.H, c, quads);
+    fix_one_output<NB, LPO>(p, sh_s, sc_s, tr_w, static_cast<int>(ent.x), static_cast<int>(ent.y), valid && static_cast<int>(ent.x) < p.n && static_cast<int>(ent.y) < p.H, c, quads);
   }
   if (any_overflow) {
     const int node_tiles = (p.H + TN - 1) / TN;
@@ -1136,10 +1154,10 @@ __global__ __launch_bounds__(kFixThreads) void l0_fix_list_kernel(L0Params p, in
       const uint32_t count = p.scr_count[tile_id];
       if (count == 0) continue;
       const int f0 = (tile_id / node_tiles) * TF, n0 = (tile_id % node_tiles) * TN;
-      for (int base = 0; base < TF * TN; base += kFixThreads / 4) {
-        const int o = base + (tid >> 2);
+      for (int base = 0; base < TF * TN; base += kFixThreads / LPO) {
+        const int o = base + (tid / LPO);
         const int f = f0 + o / TN, node = n0 + o % TN;
-        fix_one_output(p, sh_s, sc_s, f, node, f < p.n && node < p.H, c, quads);
+        fix_one_output<NB, LPO>(p, sh_s, sc_s, tr_w, f, node, f < p.n && node < p.H, c, quads);
       }
       __syncthreads();
       if (tid == 0) {
@@ -1189,7 +1207,7 @@ void launch_screened_cfg(const L0Params &p, hipStream_t s) {
   }
   const int node_tiles = (p.H + 127) / 128, frame_tiles = (p.n_rows + Cfg::TF - 1) / Cfg::TF;
   hipLaunchKernelGGL(k_scr, dim3(l0_grid(node_tiles, frame_tiles)), dim3(Cfg::THREADS), Cfg::LDS, s, p);
-  hipLaunchKernelGGL(l0_fix_kernel, dim3(node_tiles * frame_tiles), dim3(kFixThreads), 2 * sizeof(float) * p.D, s, p, Cfg::TF);
+  hipLaunchKernelGGL(l0_fix_kernel, dim3(node_tiles * frame_tiles), dim3(kFixThreads), 2 * sizeof(float) * p.D + (kFixThreads / 64) * FDNN_L0_FIX_DEPTH * 1024, s, p, Cfg::TF);
 }
 int l0_screen_wfr() {
   static const int wfr = [] {
@@ -1242,7 +1260,7 @@ void launch_l0(const L0Params &p, hipStream_t s) {
                            : p.n_rows <= 1200 ? (17.0 + 0.032 * p.n_rows) * work
                                               : 20.0 + 0.0355 * work * (p.H / 2048.0) * p.n_rows;
   const bool can_screen = !p.fma && !no_screen && (p.kernel == 0 || p.kernel == 3) && !p.tap_lin && p.wnorm && p.scr_count && p.scr_list && p.n >= 2048 &&
-                          p.D <= 8192;  // l0_fix_kernel stages one operand row pair in 8 D bytes of dynamic LDS (64 KB without an attribute)
+                          p.D <= 4096;  // l0_fix_kernel: 8 D bytes of shift / scale + 24 KB of product blocks in dynamic LDS (64 KB without an attribute)
   const bool can_chain = !p.fma && p.xt && p.wt && p.kernel != 2 && !(classic && p.kernel == 0);
   // Round 4: the screening on the int8 matrix pipe (fdnn_l0s.hip: exact 24-bit integer images of both operands, eight
   // int8 MFMA products) + the same exact recomputation of the flagged outputs.  128 x 128 tiles, 1.85 us of matrix-pipe
@@ -1250,17 +1268,48 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   static const bool no_split = std::getenv("FDNN_L0_NO_SPLIT") != nullptr;
   static const int split_min = [] {
     const char *e = std::getenv("FDNN_L0_SPLIT_MIN");
-    return e ? std::atoi(e) : 640;
+    return e ? std::atoi(e) : 560;  // whole call at 512 / 600 frames: 118 / 140 us with the 64 x 64 tiles, 121 / 136 with the screening
   }();
   const bool can_split = !p.fma && !no_split && !no_screen && (p.kernel == 0 || p.kernel == 4) && !p.tap_lin && p.xd && p.xstat && p.wd && p.wstat && p.luthalf && p.glist && p.glist_count &&
                          p.scr_count && p.scr_list && l0_split_ok(p.D, p.H);
   if (can_split && (p.kernel == 4 || p.n >= split_min)) {
     launch_l0_split(p, s);
     const int node_tiles = p.h_ld / 128, frame_tiles = (p.n_rows + 127) / 128;
+    // Variant by batch size (rocprofv3, us at 1 000 / 4 000 / 10 000 frames; LABBOOK): four lanes per output, three quads per
+    // lane and operand in flight, 256 threads: 8.7 / 11.4 / 23.8; EIGHT lanes per output (a whole 128-byte line per output
+    // and load, five round trips instead of nine): 7.3 / 13.8 / 25.0 -- fewer flagged outputs = a latency chain, many = L2
+    // gathers, where the second set of lanes only costs registers.  FDNN_L0_FIX_NB / _T / _LPO force a variant.
+    static const int force_nb = [] {
+      const char *e = std::getenv("FDNN_L0_FIX_NB");
+      return e ? std::atoi(e) : 0;
+    }();
+    static const int force_t = [] {
+      const char *e = std::getenv("FDNN_L0_FIX_T");
+      return e ? std::atoi(e) : 0;
+    }();
+    static const int force_lpo = [] {
+      const char *e = std::getenv("FDNN_L0_FIX_LPO");
+      return e ? std::atoi(e) : 0;
+    }();
+    const int nb = force_nb ? force_nb : 3;
+    const int thr = force_t == 512 ? 512 : 256;
+    const int lpo = force_lpo ? (force_lpo == 8 ? 8 : 4) : (p.n_rows < 3000 ? 8 : 4);
     // enough workgroups for 1.5 % flagged in one pass each (0.35 % on the bench batch); more is walked in further passes
-    const long expect = static_cast<long>(p.n_rows) * p.H * 3 / 200 / (kFixThreads / 4) + 8;
-    const int grid = static_cast<int>(std::min<long>(expect, 4096));
-    hipLaunchKernelGGL(l0_fix_list_kernel, dim3(grid), dim3(kFixThreads), 2 * sizeof(float) * p.D, s, p, node_tiles * frame_tiles);
+    const long expect = static_cast<long>(p.n_rows) * p.H * 3 / 200 / (thr / lpo) + 8;
+    const int grid = static_cast<int>(std::min<long>(expect, 8192));
+    const int tiles = node_tiles * frame_tiles;
+#define FDNN_FIX_LAUNCH(NB_, T_, L_) hipLaunchKernelGGL((l0_fix_list_kernel<NB_, T_, L_>), dim3(grid), dim3(T_), 2 * sizeof(float) * p.D + (T_ / 64) * NB_ * 1024, s, p, tiles)
+#define FDNN_FIX_LAUNCH_T(T_)                                                        \
+  do {                                                                               \
+    if (lpo == 8) {                                                                  \
+      if (nb >= 3) FDNN_FIX_LAUNCH(3, T_, 8); else FDNN_FIX_LAUNCH(2, T_, 8);        \
+    } else {                                                                         \
+      if (nb >= 5) FDNN_FIX_LAUNCH(5, T_, 4); else FDNN_FIX_LAUNCH(3, T_, 4);        \
+    }                                                                                \
+  } while (0)
+    if (thr == 512) FDNN_FIX_LAUNCH_T(512); else FDNN_FIX_LAUNCH_T(256);
+#undef FDNN_FIX_LAUNCH_T
+#undef FDNN_FIX_LAUNCH
     return;
   }
   if (can_screen && (p.kernel == 3 || (screened_us < (can_chain ? chain_us : tile64_us) && screened_us < tile64_us))) {
