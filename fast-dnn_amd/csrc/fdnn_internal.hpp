@@ -75,6 +75,9 @@ struct fdnn_ctx {
   hipEvent_t done = nullptr;      // last enqueued work (pool hand-over between streams, ctx_enter/ctx_leave)
   hipStream_t done_stream = nullptr;  // the stream `done` was last recorded on
   bool done_valid = false;
+  bool done_pending = false;      // work went to done_stream -- a stream that outlives this context's use of it (see
+                                  // stream_is_durable) -- after the last record: recorded when ANOTHER stream asks (ctx_enter)
+  hipStream_t durable[3] = {nullptr, nullptr, nullptr};  // streams of the context's owner (the scoring loop's), besides `stream`
   float *d_x = nullptr;           // [n][D]
   float *d_xt = nullptr;          // [4][l0_j_pad][xt_ld] layer-0 frame image (shifted, scaled, chain-major)
   int xt_ld = 0;
@@ -153,7 +156,16 @@ constexpr int kRoundFrames = 10240;
 constexpr int kChunkFrames = 2 * kRoundFrames;
 constexpr int kChunkTailSplit = 2048;
 std::vector<std::pair<int, int>> frame_chunks(int n);
+// Ordering between the streams a context is used on.  An event record costs 3-4 us of queue time behind the kernel it
+// follows, so a context whose work went to a stream that is certain to exist later -- its own, its owner's, or the null
+// stream -- only NOTES that (done_pending); the record is made when a different stream next needs the order (ctx_enter),
+// or never.  Work on a caller's stream, which the caller may destroy, is recorded at once as before.
 hipError_t ctx_enter(fdnn_ctx *c, hipStream_t s);
 void ctx_leave(fdnn_ctx *c, hipStream_t s);
+bool stream_is_durable(const fdnn_ctx *c, hipStream_t s);
+void ctx_wait_host(fdnn_ctx *c);  // host-side wait for everything ctx_leave covered
+// The per-device chain of fused soft-max launches (run_output) notes its last launch the same way: a stream that is about
+// to be destroyed must be retired from it first.
+void fuse_chain_retire_stream(int device, hipStream_t s);
 
 }  // namespace fdnn

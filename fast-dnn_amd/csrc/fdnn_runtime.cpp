@@ -140,7 +140,10 @@ int build_l0_image(fdnn_model *m) {
 void destroy_ctx(fdnn_ctx *c) {
   if (!c) return;
   DeviceGuard g(c->m->device);
-  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->stream) {
+    fuse_chain_retire_stream(c->m->device, c->stream);
+    hipStreamSynchronize(c->stream);
+  }
   hipFree(c->d_x);
   hipFree(c->d_xt);
   hipFree(c->d_l0park);
@@ -386,12 +389,22 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
 // One chain of fused soft-max launches per device (see run_output).
 struct FuseChain {
   std::mutex mu;
-  hipEvent_t ev = nullptr;  // recorded after the device's latest fused output launch
-  bool recorded = false;
+  hipEvent_t ev = nullptr;  // recorded after the device's latest fused output launch -- at once on a caller's stream;
+  bool recorded = false;    // on a durable stream (stream_is_durable) only when a launch on ANOTHER stream needs it:
+  bool pending = false;     // `pending` = the latest launch went to last_stream and `ev` does not cover it yet
+  hipStream_t last_stream = nullptr;
 };
 static FuseChain &fuse_chain(int device) {
   static FuseChain chains[64];
   return chains[device & 63];
+}
+void fuse_chain_retire_stream(int device, hipStream_t s) {
+  FuseChain &fc = fuse_chain(device);
+  std::lock_guard<std::mutex> lk(fc.mu);
+  if (fc.pending && fc.last_stream == s && fc.ev) {
+    fc.recorded = hipEventRecord(fc.ev, s) == hipSuccess;
+    fc.pending = false;
+  }
 }
 
 int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *d_out, hipStream_t s, const Taps *taps,
@@ -455,10 +468,26 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
       FuseChain &fc = fuse_chain(m->device);
       std::lock_guard<std::mutex> lk(fc.mu);
       if (!fc.ev) HIP_TRY(hipEventCreateWithFlags(&fc.ev, hipEventDisableTiming | hipEventDisableSystemFence));
-      if (fc.recorded) HIP_TRY(hipStreamWaitEvent(s, fc.ev, 0));  // (a wait on the stream's own last record is free)
+      static const bool eager = std::getenv("FDNN_EAGER_EVENTS") != nullptr;
+      if (fc.last_stream != s || !(fc.pending || fc.recorded)) {  // (same stream as the previous fused launch: in order already)
+        if (fc.pending) {  // the deferred record: the tail of the previous launch's stream is behind that launch
+          fc.pending = false;
+          fc.recorded = false;
+          HIP_TRY(hipEventRecord(fc.ev, fc.last_stream));
+          fc.recorded = true;
+        }
+        if (fc.recorded) HIP_TRY(hipStreamWaitEvent(s, fc.ev, 0));
+      }
       fdnn::launch_qgemm_output(g, s);
-      HIP_TRY(hipEventRecord(fc.ev, s));
-      fc.recorded = true;
+      fc.last_stream = s;
+      if (stream_is_durable(c, s) && !eager) {
+        fc.pending = true;
+      } else {
+        fc.pending = false;
+        fc.recorded = false;
+        HIP_TRY(hipEventRecord(fc.ev, s));
+        fc.recorded = true;
+      }
     } else {
       fdnn::launch_qgemm_output(g, s);
     }
@@ -586,13 +615,35 @@ std::vector<std::pair<int, int>> frame_chunks(int n) {
   return out;
 }
 
+bool stream_is_durable(const fdnn_ctx *c, hipStream_t s) {
+  return s == nullptr || s == c->stream || s == c->durable[0] || s == c->durable[1] || s == c->durable[2];
+}
 hipError_t ctx_enter(fdnn_ctx *c, hipStream_t s) {
-  if (c->done_valid && c->done_stream == s) return hipSuccess;  // same stream: already in order
+  if (c->done_stream == s && (c->done_valid || c->done_pending)) return hipSuccess;  // same stream: already in order
+  if (c->done_pending) {  // the deferred record: the tail of done_stream covers everything the context enqueued there
+    c->done_pending = false;
+    const hipError_t e = hipEventRecord(c->done, c->done_stream);
+    c->done_valid = e == hipSuccess;
+    if (e != hipSuccess) return e;
+  }
   return hipStreamWaitEvent(s, c->done, 0);
 }
 void ctx_leave(fdnn_ctx *c, hipStream_t s) {
-  c->done_valid = hipEventRecord(c->done, s) == hipSuccess;
+  static const bool eager = std::getenv("FDNN_EAGER_EVENTS") != nullptr;  // (measurements: every record made at once, as before round 4)
   c->done_stream = s;
+  if (stream_is_durable(c, s) && !eager) {
+    c->done_pending = true;
+    c->done_valid = false;
+    return;
+  }
+  c->done_pending = false;
+  c->done_valid = hipEventRecord(c->done, s) == hipSuccess;
+}
+void ctx_wait_host(fdnn_ctx *c) {
+  if (c->done_pending)
+    hipStreamSynchronize(c->done_stream);
+  else if (c->done_valid)
+    hipEventSynchronize(c->done);
 }
 
 void release_ctx(fdnn_ctx *c, hipStream_t s) {
@@ -610,7 +661,7 @@ void release_ctx(fdnn_ctx *c, hipStream_t s) {
     }
   }
   if (victim) {
-    hipEventSynchronize(victim->done);
+    ctx_wait_host(victim);
     destroy_ctx(victim);
   }
 }
@@ -636,7 +687,7 @@ int calculate_on_one_device(fdnn_model *m, const float *x, int n, int dim, int b
   int rc = acquire_ctx(m, n, &c);
   if (rc) return rc;
   hipStream_t s = c->stream;
-  hipError_t e = hipStreamWaitEvent(s, c->done, 0);
+  hipError_t e = ctx_enter(c, s);
   if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x, sizeof(float) * size_t(n) * dim, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
     rc = run_hidden(c, c->d_x, s, nullptr);

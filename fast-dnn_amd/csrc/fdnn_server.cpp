@@ -169,15 +169,17 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
     // read them: it waits for `tail_done` there.
     const size_t D = size_t(s->m->hm.hdr.in_dim), O = size_t(s->m->hm.hdr.out_dim);
     bool first = true;
-    for (const auto &ch : chunks) {
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+      const auto &ch = chunks[ci];
       c->n = ch.second;
       rc = fdnn::run_hidden(c, d_x + size_t(ch.first) * D, cs, nullptr);
       if (rc) break;
-      if (!first) HIP_TRY(hipStreamWaitEvent(cs, sl.tail_done, 0));
+      if (!first && overlap) HIP_TRY(hipStreamWaitEvent(cs, sl.tail_done, 0));
       rc = fdnn::run_output(c, 0, ch.second, d_masks ? d_masks + size_t(ch.first) * O : nullptr, d_out + size_t(ch.first) * O, cs,
                             nullptr, nullptr, overlap ? s->s_tail : nullptr, overlap ? sl.gemm_done : nullptr);
       if (rc) break;
-      HIP_TRY(hipEventRecord(sl.tail_done, overlap ? s->s_tail : cs));
+      // (without the overlap everything is on the compute stream, in order; a record is 3-4 us of queue time)
+      if (overlap && ci + 1 < chunks.size()) HIP_TRY(hipEventRecord(sl.tail_done, s->s_tail));
       first = false;
     }
     c->n = n;
@@ -454,6 +456,9 @@ int fdnn_server_create(fdnn_model *m, int max_frames, int depth, fdnn_server **o
     rc = fdnn::make_ctx(m, max_frames, &sl.ctx, /*lean=*/true);
     if (rc) break;
     e = hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking);
+    sl.ctx->durable[0] = s->s_main;  // the loop's streams outlive the slot's context: its ordering records can wait until
+    sl.ctx->durable[1] = s->s_tail;  // another stream asks for them (fdnn::ctx_leave)
+    sl.ctx->durable[2] = sl.stream;
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.gemm_done, hipEventDisableTiming | hipEventDisableSystemFence);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.tail_done, hipEventDisableTiming | hipEventDisableSystemFence);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sl.staged, hipEventDisableTiming);
@@ -488,6 +493,10 @@ void fdnn_server_free(fdnn_server *s) {
     if (sl.used && sl.done) hipEventSynchronize(sl.done);
     if (sl.stream) hipStreamSynchronize(sl.stream);
   }
+  for (Slot &sl : s->slots)
+    if (sl.stream) fdnn::fuse_chain_retire_stream(s->m->device, sl.stream);
+  if (s->s_main) fdnn::fuse_chain_retire_stream(s->m->device, s->s_main);  // (the device's chain of fused launches may still name them)
+  if (s->s_tail) fdnn::fuse_chain_retire_stream(s->m->device, s->s_tail);
   if (s->s_main) hipStreamSynchronize(s->s_main);
   if (s->s_tail) hipStreamSynchronize(s->s_tail);
   for (Slot &sl : s->slots) {
