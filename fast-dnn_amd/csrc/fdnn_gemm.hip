@@ -51,6 +51,9 @@
 #ifndef FDNN_FUSE_PARTS
 #define FDNN_FUSE_PARTS 2  // parts of the fused soft-max's row-sum exchange (one per 32-frame block at most)
 #endif
+#ifndef FDNN_FUSE_SLEEP
+#define FDNN_FUSE_SLEEP 16  // 64-cycle units between two polls of a frame tile's arrival counter
+#endif
 #ifndef FDNN_SMALL_STAGES
 #define FDNN_SMALL_STAGES 3  // ring depth of the 256-node x 32-frame tile (4: no change measured)
 #endif
@@ -157,6 +160,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
   }
   if (mt >= MT || nt >= NT) return;
   const int m0 = mt * G_BM, f0 = nt * FT;
+  if (FUSED && p.fuse_stagger > 0 && static_cast<int>(blockIdx.x) < 8 * MT) {
+    // The first round's workgroups all start at once and stay in step: every CU reaches its store phase (328 KB of
+    // probabilities per tile) at the same time, and that burst drains at HBM write speed / 256 per CU while the memory sits
+    // idle during the k-loops.  A start offset per frame tile spreads the phases; later rounds inherit it.
+    for (int i = (nt & 7) * p.fuse_stagger; i > 0; --i) __builtin_amdgcn_s_sleep(8);
+  }
 
   const size_t ldw = static_cast<size_t>(p.ldw), lda = static_cast<size_t>(p.lda);
   // per-lane source of the staging loads: row = slab*RPI + lane/LPR, chunk swizzled by
@@ -567,7 +576,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     // leavers at [7]; give-up flags per tile: bit = part.  Measured, 10 000 x 8000: one part 229-234 us, two 220-222,
     // three 228, five 248 (every part is two more barriers, an atomic and a gather).
     constexpr int kParts = FDNN_FUSE_PARTS < NF ? FDNN_FUSE_PARTS : NF;  // block ni belongs to part ni * kParts / NF
-    auto part_lo = [](int part) { return (part * NF + kParts - 1) / kParts; };  // first block of a part (part_lo(kParts) = NF)
+#ifndef FDNN_FUSE_SPLIT0
+#define FDNN_FUSE_SPLIT0 2  // two parts: 32-frame blocks in the first one (0 = half, rounded up); 320-frame tiles, 10 000 x 8000: 2 -> 220.6 us, 3 -> 222.5, 4 -> 228
+#endif
+    constexpr int kSplit0 = (kParts == 2 && FDNN_FUSE_SPLIT0 > 0) ? (FDNN_FUSE_SPLIT0 < NF ? FDNN_FUSE_SPLIT0 : NF - 1) : 0;
+    auto part_lo = [](int part) { return kSplit0 ? (part == 0 ? 0 : part == 1 ? kSplit0 : NF) : (part * NF + kParts - 1) / kParts; };  // first block of a part (part_lo(kParts) = NF)
+    auto block_part = [](int ni) { return kSplit0 ? (ni < kSplit0 ? 0 : 1) : ni * kParts / NF; };
     auto exp_block = [&](int ni) {
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi) {
@@ -608,13 +622,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
       if (half == 0) Pw[wm * FT + arow0 + 32 * ni + frow] = tot;
     };
 #if FDNN_GEMM_DEBUG & 64
-    long long tf[6];
+    long long tf[6], tp[2 * kParts + 1], tw[kParts];
+#define FDNN_CLK(x) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
     tf[0] = tf[1] = tf[2] = tf[3] = __builtin_readcyclecounter();
 #endif
     float *gS = p.fuse_s + (static_cast<size_t>(nt) * MT + mt) * FT;
     uint32_t *cnt = p.fuse_cnt + 8 * nt;  // {arrived part 0 .. kParts - 1, ..., left at [7]}: all zero between launches
     // frame row f of the tile belongs to block (f % (32 NF)) / 32 of its wave half
-    auto part_of_row = [&](int f) { return ((f % (32 * NF)) >> 5) * kParts / NF; };
+    auto part_of_row = [&](int f) { return block_part((f % (32 * NF)) >> 5); };
     auto publish = [&](int part) {
       __syncthreads();  // the part's Pw entries are complete
       if (tid < FT / 4 && part_of_row(4 * tid) == part) {
@@ -670,9 +685,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     auto collect = [&](int part) {
       if (tid == 0) {
         int ok = (p.debug & 4096) && mt % 3 == part % 3 ? 0 : 1, spins = 0;  // FDNN_GEMM_DEBUG=4096 (tests): some node tiles "give up" on one part
-        while (ok && __hip_atomic_load(cnt + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < static_cast<uint32_t>(MT)) {
-          __builtin_amdgcn_s_sleep(16);
-          if (++spins > (1 << 15)) {  // tens of milliseconds (a legitimate wait is microseconds): something keeps this frame tile's other workgroups off the chip
+        while (!(FDNN_GEMM_DEBUG & 256) && ok && __hip_atomic_load(cnt + part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < static_cast<uint32_t>(MT)) {  // (256, timing build: no wait)
+          __builtin_amdgcn_s_sleep(FDNN_FUSE_SLEEP);
+          if (++spins > (1 << 15) * 16 / FDNN_FUSE_SLEEP) {  // tens of milliseconds (a legitimate wait is microseconds): something keeps this frame tile's other workgroups off the chip
             ok = 0;
             break;
           }
@@ -681,6 +696,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
         if (!ok) gave_up |= 1u << part;
       }
       __syncthreads();
+#if FDNN_GEMM_DEBUG & 64
+      FDNN_CLK(tw[part]);
+#endif
       if (ok_s[0] != 0) {
         totals(part);
       } else if (tid < FT && part_of_row(tid) == part) {
@@ -709,7 +727,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
 #elif defined(FDNN_FUSE_NT_STORE)
         if (ff < p.n && ncol0 + col + 4 <= p.rows) __builtin_nontemporal_store(v, reinterpret_cast<v4f_t *>(p.final + static_cast<size_t>(ff) * p.rows + ncol0 + col));
 #else
+#if FDNN_GEMM_DEBUG & 128  // (timing build: the probabilities do not leave)
+        if (ff < 0 && ncol0 + col + 4 <= p.rows) store_wt(p.final + static_cast<size_t>(ff) * p.rows + ncol0 + col, v);
+#else
         if (ff < p.n && ncol0 + col + 4 <= p.rows) store_wt(p.final + static_cast<size_t>(ff) * p.rows + ncol0 + col, v);
+#endif
 #endif
       }
     };
@@ -717,18 +739,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     for (int part = 0; part < kParts; ++part) {
 #pragma unroll
       for (int ni = 0; ni < NF; ++ni)
-        if (ni * kParts / NF == part) exp_block(ni);
+        if (block_part(ni) == part) exp_block(ni);
       publish(part);
     }
 #if FDNN_GEMM_DEBUG & 64
     tf[2] = __builtin_readcyclecounter();
 #endif
+#if FDNN_GEMM_DEBUG & 64
+    FDNN_CLK(tp[0]);
+#endif
 #pragma unroll
     for (int part = 0; part < kParts; ++part) {
       collect(part);
+#if FDNN_GEMM_DEBUG & 64
+      FDNN_CLK(tp[2 * part + 1]);
+#endif
 #pragma unroll
       for (int ni = 0; ni < NF; ++ni)
-        if (ni * kParts / NF == part) scale_store(ni);
+        if (block_part(ni) == part) scale_store(ni);
+#if FDNN_GEMM_DEBUG & 64
+      FDNN_CLK(tp[2 * part + 2]);  // (timing build: the part's stores have been acknowledged)
+#endif
     }
     // ---- leaving.  A workgroup that gave up on a part has stored that part's block unscaled and raises a flag (bit = part); the
     // LAST workgroup to leave the frame tile -- every sum has been published by then -- scales such blocks and lowers the
@@ -789,6 +820,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     if (tid == 0 && (blockIdx.x % 149) == 0)
       printf("FUSED %4d: prologue %lld first-stage %lld mainloop %lld | exp + publish (all parts) %lld collect + scale + store %lld | total %lld\n", blockIdx.x,
              ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], tf[2] - ts[3], tf[5] - tf[2], tf[5] - ts[0]);
+    if (tid == 0 && (blockIdx.x % 149) == 0)
+      printf("PARTS %4d: poll0 %d totals0 %d store0 %d poll1 %d totals1 %d store1 %d\n", blockIdx.x, static_cast<int>(tw[0] - tp[0]), static_cast<int>(tp[1] - tw[0]),
+             static_cast<int>(tp[2] - tp[1]), static_cast<int>(tw[kParts - 1] - tp[2 * kParts - 2]), static_cast<int>(tp[2 * kParts - 1] - tw[kParts - 1]),
+             static_cast<int>(tp[2 * kParts] - tp[2 * kParts - 1]));
 #endif
     return;
   }

@@ -104,6 +104,7 @@ struct QGemmParams {
   float *fuse_s;
   uint32_t *fuse_cnt;
   uint32_t *fuse_flag;
+  int fuse_stagger;       // fused soft-max: start delay of the first round's frame tile j = (j % 8) * this many 512-cycle naps (see qgemm_kernel)
   unsigned long long *fuse_giveups;  // per model: tiles that had to be scaled after the fact (a workgroup gave up waiting); null = not counted
   // accumulator probe of the PRODUCTION output instances (parity tests only; null otherwise): the int32 accumulators of
   // every probe_stride-th frame, [ceil(n / probe_stride)][rows] -- a wave-uniform branch in front of the epilogue

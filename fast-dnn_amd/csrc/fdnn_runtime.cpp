@@ -455,6 +455,11 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
     g.fuse_cnt = c->d_fuse_cnt;
     g.fuse_flag = c->d_fuse_flag;
     g.fuse_giveups = m->d_l0_stats ? m->d_l0_stats + 2 : nullptr;
+    static const int stagger = [] {
+      const char *e = std::getenv("FDNN_FUSE_STAGGER");
+      return e ? std::atoi(e) : 0;
+    }();
+    g.fuse_stagger = stagger;
   }
   {
     ProfScope ps(m, s, FDNN_PROF_OUTPUT);
