@@ -3,8 +3,9 @@ import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from fast_dnn_amd import api, formats as F
-p = "/tmp/fdnn_net_seed1_gauss.bin"
-F.ensure_model_file(p, F.NET_TOPOLOGY, seed=1, mode="gauss")
+mode = os.environ.get("MODE", "gauss")
+p = f"/tmp/fdnn_net_seed1_{mode}.bin"
+F.ensure_model_file(p, F.NET_TOPOLOGY, seed=1, mode=mode)
 dnn = api.QuantizedDnn.loadFromFile(p)
 n = int(os.environ.get("N", "10000"))
 x = torch.from_numpy(F.synth_features(n, 432, seed=5)).cuda()
