@@ -483,6 +483,44 @@ def test_fused_softmax_under_many_streams_and_two_models(net_model_path, tmp_mod
     dnn2.delete()
 
 
+@pytest.mark.parametrize("n", [10000, 1000, 100])
+def test_deferred_ordering_records_between_streams(net_model_path, n):
+    """A context whose work went to a stream that outlives it (its own, the null stream) only notes that and records its
+    hand-over event when ANOTHER stream next uses it (fdnn_runtime.cpp: ctx_enter / ctx_leave, the device's chain of fused
+    launches in run_output); work on a caller-created stream is recorded at once.  One thread, no synchronisation between
+    the calls, the pooled context -- and its scratch buffers -- handed from stream to stream: null stream -> caller
+    stream -> host call (the context's own stream) -> null stream -> second caller stream, different frames each time.
+    Every result equals the one of the same call made alone.  (CalculationContext is per call in the reference,
+    dnn.cc:146-165: nothing to order there.)"""
+    import torch
+
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    O = dnn.outputDimension()
+    xs = [torch.from_numpy(F.synth_features(n, 432, seed=70 + i)).cuda() for i in range(5)]
+    refs = []
+    for x in xs:  # each call alone
+        r = torch.empty((n, O), dtype=torch.float32, device="cuda")
+        dnn.calculate_device(x.data_ptr(), n, r.data_ptr(), 0)
+        torch.cuda.synchronize()
+        refs.append(r)
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(3):
+        outs = [torch.zeros((n, O), dtype=torch.float32, device="cuda") for _ in range(5)]
+        torch.cuda.synchronize()
+        dnn.calculate_device(xs[0].data_ptr(), n, outs[0].data_ptr(), 0)               # null stream: noted, not recorded
+        dnn.calculate_device(xs[1].data_ptr(), n, outs[1].data_ptr(), sa.cuda_stream)  # caller stream: the deferred record, then its own
+        host = dnn.calculate(xs[2].cpu().numpy())                                        # the context's own stream
+        dnn.calculate_device(xs[3].data_ptr(), n, outs[3].data_ptr(), 0)
+        dnn.calculate_device(xs[4].data_ptr(), n, outs[4].data_ptr(), sb.cuda_stream)
+        torch.cuda.synchronize()
+        for i in (0, 1, 3, 4):
+            assert torch.equal(outs[i], refs[i]), (rep, i)
+        assert np.array_equal(host, refs[2].cpu().numpy()), rep
+    if not os.environ.get("FDNN_FUSE_NORM"):
+        assert dnn.fuseGiveups() == 0
+    dnn.delete()
+
+
 @pytest.mark.parametrize("out_dim,n", [(8000, 10000), (1003, 3000), (8000, 100), (1003, 37)])
 def test_bit_mask_entry_points_equal_the_byte_mask_ones(net_model_path, tmp_models, out_dim, n):
     """fdnn_ctx_lazy_output_batch_bits[_device]: the LazyContext contract (dnn.cc:355-392) with the active set handed over
