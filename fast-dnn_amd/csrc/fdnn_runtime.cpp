@@ -230,6 +230,12 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
   if (e == hipSuccess && !lean)
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_out_pin), sizeof(float) * kPinFrames * h.out_dim, hipHostMallocMapped);
   if (e == hipSuccess && !lean) e = hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_out_pin), c->h_out_pin, 0);
+  // The hipMemsets above are ordered on the NULL stream and return before they have run; the context's kernels go to
+  // non-blocking streams, which do not wait for it.  Without this wait a new context's first kernels could start first and
+  // have their counters (flagged-output list, fused soft-max arrivals) zeroed under them: a partly walked list -- a few
+  // layer-0 bytes left at their screened value -- or a frame tile waiting for arrivals that were wiped.  Seen as one failure
+  // in ten of the many-streams test (contexts are created while other callers' kernels run), never in a single-stream run.
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming | hipEventDisableSystemFence);  // (orders streams of one device only: no system-scope flush per record)
   if (e != hipSuccess) {
