@@ -483,6 +483,55 @@ def test_fused_softmax_under_many_streams_and_two_models(net_model_path, tmp_mod
     dnn2.delete()
 
 
+def test_new_contexts_while_other_callers_keep_the_device_busy(net_model_path):
+    """A context's scratch counters (layer 0's list of flagged outputs, the fused soft-max's arrival counters) are zeroed
+    when the context is made, and that must have HAPPENED before its first kernel runs on a caller's non-blocking stream
+    (make_ctx waits for its null-stream memsets).  Contexts are made on a model's first calls, so: a fresh model, eight
+    caller threads starting at once on their own streams, three 10 000-frame calls each, twelve times over -- every result
+    equal to the single-stream one, no tile of the fused soft-max given up.  (Before the wait: one failure in ten of the
+    many-streams test, a few hundred rows with layer-0 bytes left at their screened value.)"""
+    import threading
+
+    import torch
+
+    n, T = 10000, 8
+    x = torch.from_numpy(F.synth_features(n, 432, seed=43)).cuda()
+    streams = [torch.cuda.Stream() for _ in range(T)]
+    ref = None
+    for rep in range(12):
+        dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+        O = dnn.outputDimension()
+        if ref is None:
+            ref = torch.empty((n, O), dtype=torch.float32, device="cuda")
+            dnn.calculate_device(x.data_ptr(), n, ref.data_ptr(), 0)
+            torch.cuda.synchronize()
+            dnn.delete()
+            dnn = api.QuantizedDnn.loadFromFile(net_model_path)  # (an empty context pool again)
+        outs = [torch.zeros((n, O), dtype=torch.float32, device="cuda") for _ in range(T)]
+        torch.cuda.synchronize()
+        bad = []
+        go = threading.Barrier(T)
+
+        def caller(t):
+            go.wait()
+            for r in range(3):
+                dnn.calculate_device(x.data_ptr(), n, outs[t].data_ptr(), streams[t].cuda_stream)
+                streams[t].synchronize()
+                with torch.cuda.stream(streams[t]):
+                    if not torch.equal(outs[t], ref):
+                        bad.append((t, r))
+
+        th = [threading.Thread(target=caller, args=(t,)) for t in range(T)]
+        for h in th:
+            h.start()
+        for h in th:
+            h.join()
+        assert not bad, (rep, bad)
+        if not os.environ.get("FDNN_FUSE_NORM"):
+            assert dnn.fuseGiveups() == 0, rep
+        dnn.delete()
+
+
 @pytest.mark.parametrize("n", [10000, 1000, 100])
 def test_deferred_ordering_records_between_streams(net_model_path, n):
     """A context whose work went to a stream that outlives it (its own, the null stream) only notes that and records its
