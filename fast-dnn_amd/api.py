@@ -59,6 +59,8 @@ SIGNATURES = {
     "fdnn_model_device": (C.c_int, [C.c_void_p]),
     "fdnn_model_set_l0_fma": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_set_l0_kernel": (C.c_int, [C.c_void_p, C.c_int]),
+    "fdnn_debug_set_chain": (C.c_int, [C.c_int, C.c_int]),
+    "fdnn_debug_chain_clocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]),
     "fdnn_calculate": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, C.c_int, _c_f32p]),
     "fdnn_calculate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "fdnn_ctx_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -185,6 +187,12 @@ def device_count() -> int:
     return int(lib().fdnn_device_count())
 
 
+def set_chain(mode: int, min_frames: int = 0) -> None:
+    """How the int8 hidden layers run (process-wide; results are bit-identical): 1 = one persistent launch for batches of
+    at least min_frames frames, 0 = one launch per layer, -1 = the default."""
+    _check(lib().fdnn_debug_set_chain(int(mode), int(min_frames)))
+
+
 class LazyContext:
     """``QuantizedDnn.LazyContext`` (QuantizedDnn.java:72-98)."""
 
@@ -247,6 +255,16 @@ class LazyContext:
     def calculateForOutputNodesBatchDevice(self, d_masks: int, d_out: int, first: int, count: int, stream: int = 0) -> None:
         _check(lib().fdnn_ctx_lazy_output_batch_device(self.handle, first, count, C.c_void_p(d_masks), C.c_void_p(d_out),
                                                        C.c_void_p(stream)))
+
+    def chainClocks(self, cap_tasks: int, fetch: bool = False):
+        """Measurement builds (-DFDNN_CHAIN_CLK=1): arm (fetch=False) / read the chained kernel's per-task phase clocks."""
+        if not fetch:
+            _check(lib().fdnn_debug_chain_clocks(self.handle, None, int(cap_tasks)))
+            return None
+        buf = np.zeros(8 + 10 * int(cap_tasks), dtype=np.int64)
+        _check(lib().fdnn_debug_chain_clocks(self.handle, buf.ctypes.data_as(C.POINTER(C.c_longlong)), int(cap_tasks)))
+        k = int(buf[0] & 0xffffffff)
+        return buf[8:8 + 10 * min(k, int(cap_tasks))].reshape(-1, 10)
 
     def hiddenActivations(self) -> np.ndarray:
         out = np.empty((self.inputVectorCount, self.dnn.hiddenDimension()), dtype=np.uint8)

@@ -96,6 +96,10 @@ struct fdnn_ctx {
   float *d_fuse_s = nullptr;        // fused soft-max: per-tile row sums [n_pad / tile][rows_pad / 256][tile] floats
   uint32_t *d_fuse_cnt = nullptr;   // {arrived part 0 .., left at [7]} per frame tile; zero between launches
   uint32_t *d_fuse_flag = nullptr;  // per tile: parts a workgroup left unscaled ("gave up waiting"); zero between launches
+  uint32_t *d_chain_ctl = nullptr;   // chained hidden layers (fdnn_chain.hip): queue heads [0..7], workgroups that left [8]
+  uint32_t *d_chain_done = nullptr;  // [frame tiles][layers of the chain] node tiles finished; zero between launches
+  long long *d_chain_clk = nullptr;  // measurement builds only: per-task phase clocks
+  int chain_clk_cap = 0;
   uint64_t *d_mask_bits = nullptr;  // [n][ceil(O/64)] the batched lazy call's mask as bits (launch_mask_pack)
   float *d_comp = nullptr;          // host lazy batches: compacted result rows (allocated on first use)
   size_t comp_floats = 0;

@@ -126,6 +126,36 @@ bool qgemm_fused_ok(const QGemmParams &p);
 void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s);
 void launch_qgemm_output(const QGemmParams &p, hipStream_t s);
 
+// The int8 HIDDEN layers of a pass in one persistent launch (fdnn_chain.hip): tasks (layer, frame tile, node tile) drawn
+// from per-XCD queues, a task waits only for its own frame tile's node tiles of the layer before.  All hidden layers of
+// a net have the same shape (README.md:10), so one set of sizes serves every layer.
+constexpr int kMaxChainLayers = 8;
+struct QChainLayer {
+  const int8_t *w;         // [rows_pad][ldw]
+  const float *bias;       // [rows_pad]
+  const int32_t *wsum;     // [rows_pad]
+  const int32_t *fix_grp;  // as QGemmParams
+  const void *fix_ent;     // null: no risky pairs in this layer
+  float coef, rcp_coef;
+};
+struct QChainParams {
+  QChainLayer layer[kMaxChainLayers];
+  int n_layers;
+  int8_t *act[2];          // layer i reads act[i & 1] and writes act[(i & 1) ^ 1]; rows [n_pad][lda]
+  const uint8_t *lut2;     // half-step sigmoid table
+  int rows, rows_pad, K, ldw, lda, n, n_pad;
+  int frame_tile;          // 320 or 256
+  uint32_t *ctl;           // [16]: queue heads [0..7], workgroups that have left [8]; zero between launches
+  uint32_t *done;          // [n_pad / frame_tile][n_layers] node tiles finished; zero between launches
+  unsigned long long *faults;  // waits that ran into their bound (never; observable through fdnn_model_fuse_giveups' sibling)
+  long long *clk;          // measurement builds (FDNN_CHAIN_CLK): [8 + clk_cap * 10] phase clocks per task, else null
+  int clk_cap;
+};
+bool qchain_ok(int rows_pad, int K, int n, int n_layers);
+void qchain_set_mode(int mode, int min_frames);  // fdnn_debug_set_chain
+int qchain_frame_tile(int rows_pad, int n);
+void launch_qchain(const QChainParams &p, hipStream_t s);
+
 // bits[f][w] bit b = mask[f][64 w + b] != 0  (words per row = ceil(rows / 64); bits past the row are zero).  The lazy
 // contract's byte masks (80 MB for 10 000 frames x 8000 nodes) are read once here, at HBM speed, instead of inside the
 // output GEMM's epilogue.

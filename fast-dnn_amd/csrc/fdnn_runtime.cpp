@@ -163,6 +163,9 @@ void destroy_ctx(fdnn_ctx *c) {
   hipFree(c->d_fuse_s);
   hipFree(c->d_fuse_cnt);
   hipFree(c->d_fuse_flag);
+  hipFree(c->d_chain_ctl);
+  hipFree(c->d_chain_done);
+  hipFree(c->d_chain_clk);
   if (c->h_mask_pin) hipHostFree(c->h_mask_pin);
   if (c->h_out_pin) hipHostFree(c->h_out_pin);
   if (c->done) hipEventDestroy(c->done);
@@ -223,6 +226,13 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
     alloc(reinterpret_cast<void **>(&c->d_fuse_flag), sizeof(uint32_t) * tiles * mt);
     if (e == hipSuccess) e = hipMemset(c->d_fuse_cnt, 0, sizeof(uint32_t) * 8 * tiles);
     if (e == hipSuccess) e = hipMemset(c->d_fuse_flag, 0, sizeof(uint32_t) * tiles * mt);
+  }
+  {  // chained hidden layers: queue heads + leave counter, per frame tile and layer the finished node tiles (zero between launches)
+    const size_t tiles = npt / 256 + 2;
+    alloc(reinterpret_cast<void **>(&c->d_chain_ctl), sizeof(uint32_t) * 16);
+    alloc(reinterpret_cast<void **>(&c->d_chain_done), sizeof(uint32_t) * tiles * fdnn::kMaxChainLayers);
+    if (e == hipSuccess) e = hipMemset(c->d_chain_ctl, 0, sizeof(uint32_t) * 16);
+    if (e == hipSuccess) e = hipMemset(c->d_chain_done, 0, sizeof(uint32_t) * tiles * fdnn::kMaxChainLayers);
   }
   if (e == hipSuccess && !lean)  // (at least one padded row of slack)
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mask_pin), std::max(size_t(kPinFrames) * h.out_dim, size_t(max_rows_pad)), hipHostMallocMapped);
@@ -371,6 +381,56 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
   run_layer0(c, d_x, s, taps);
   int cur = 0;
   if (taps && taps->u8_acts) snapshot_acts(c, cur, taps->u8_acts, s);
+  // Large batches, no taps: the int8 hidden layers as ONE persistent launch (fdnn_chain.hip) -- tasks (layer, frame tile,
+  // node tile) drawn from per-XCD queues, each waiting only for its own frame tile's node tiles of the layer before.
+  const int n_hid = h.n_q - 1;
+  bool chain = !taps && n_hid >= 2 && c->d_chain_ctl != nullptr &&
+               fdnn::qchain_ok(h.q[0].rows_pad, h.q[0].cols_pad - fdnn::kRowSkew, c->n, std::min(n_hid, fdnn::kMaxChainLayers));
+  for (int qi = 0; chain && qi < n_hid; ++qi)
+    chain = h.q[qi].fastdiv_ok && h.q[qi].rows == h.q[0].rows && h.q[qi].rows_pad == h.q[0].rows_pad && h.q[qi].cols_pad == h.q[0].cols_pad;
+  if (chain) {
+    const uint8_t *B = m->d_blob;
+    for (int q0 = 0; q0 < n_hid; q0 += fdnn::kMaxChainLayers) {  // (nets deeper than kMaxChainLayers + 1: several chains)
+      const int nl = std::min(fdnn::kMaxChainLayers, n_hid - q0);
+      fdnn::QChainParams g{};
+      for (int i = 0; i < nl; ++i) {
+        const QLayerDesc &d = h.q[q0 + i];
+        fdnn::QChainLayer &L = g.layer[i];
+        L.w = reinterpret_cast<const int8_t *>(B + d.off_w);
+        L.bias = reinterpret_cast<const float *>(B + d.off_bias);
+        L.wsum = reinterpret_cast<const int32_t *>(B + d.off_wsum);
+        L.fix_grp = d.n_fix > 0 ? reinterpret_cast<const int32_t *>(B + d.off_fix_grp) : nullptr;
+        L.fix_ent = d.n_fix > 0 ? B + d.off_fix_ent : nullptr;
+        L.coef = d.coef;
+        L.rcp_coef = d.rcp_coef;
+      }
+      g.n_layers = nl;
+      g.act[0] = c->d_act[cur];
+      g.act[1] = c->d_act[cur ^ 1];
+      g.lut2 = B + h.off_lut2;
+      g.rows = h.q[0].rows;
+      g.rows_pad = h.q[0].rows_pad;
+      g.K = h.q[0].cols_pad - fdnn::kRowSkew;
+      g.ldw = h.q[0].cols_pad;
+      g.lda = c->act_ld;
+      g.n = c->n;
+      g.frame_tile = fdnn::qchain_frame_tile(g.rows_pad, c->n);
+      g.n_pad = round_up(c->n, g.frame_tile);
+      g.ctl = c->d_chain_ctl;
+      g.done = c->d_chain_done;
+      g.faults = m->d_l0_stats ? m->d_l0_stats + 3 : nullptr;
+      g.clk = c->d_chain_clk;
+      g.clk_cap = c->chain_clk_cap;
+      {
+        ProfScope ps(m, s, FDNN_PROF_HIDDEN);
+        fdnn::launch_qchain(g, s);
+      }
+      cur ^= nl & 1;
+    }
+    c->last = cur;
+    HIP_TRY(hipGetLastError());
+    return FDNN_OK;
+  }
   for (int qi = 0; qi < h.n_q - 1; ++qi) {
     fdnn::QGemmParams g = prepare_qlayer(c, h.q[qi], c->d_act[cur], c->n, s);
     g.act_out = c->d_act[cur ^ 1];
@@ -860,6 +920,34 @@ int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind) {
   if (!m) return fail(FDNN_E_ARG, "null model");
   if (kind < 0 || kind > 4) return fail(FDNN_E_ARG, "layer-0 kernel kind must be 0 .. 4");
   m->l0_kernel = kind;
+  return FDNN_OK;
+}
+
+int fdnn_debug_set_chain(int mode, int min_frames) {
+  if (mode < -1 || mode > 1) return fail(FDNN_E_ARG, "chain mode must be -1, 0 or 1");
+  fdnn::qchain_set_mode(mode, min_frames);
+  return FDNN_OK;
+}
+
+int fdnn_debug_chain_clocks(fdnn_ctx *c, long long *out, int cap_tasks) {
+  if (!c || cap_tasks <= 0) return fail(FDNN_E_ARG, "bad argument");
+  DeviceGuard g(c->m->device);
+  const size_t words = 8 + size_t(cap_tasks) * 10;
+  if (!out) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_chain_clk) hipFree(c->d_chain_clk);
+    c->d_chain_clk = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_chain_clk), words * sizeof(long long)));
+    HIP_TRY(hipMemset(c->d_chain_clk, 0, words * sizeof(long long)));
+    HIP_TRY(hipDeviceSynchronize());
+    c->chain_clk_cap = cap_tasks;
+    return FDNN_OK;
+  }
+  if (!c->d_chain_clk || cap_tasks > c->chain_clk_cap) return fail(FDNN_E_STATE, "no clock buffer of that size");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, c->d_chain_clk, words * sizeof(long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(c->d_chain_clk, 0, 8 * sizeof(long long)));
+  HIP_TRY(hipDeviceSynchronize());
   return FDNN_OK;
 }
 

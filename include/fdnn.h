@@ -258,6 +258,19 @@ FDNN_API int fdnn_debug_frame_chunks(int n, int *chunks, int cap);
  * available (batches of 2048 frames and more, no taps). */
 FDNN_API int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind);
 
+/* How the int8 hidden layers run (tests / measurements only; results are bit-identical): mode 1 = as ONE persistent
+ * launch (fdnn_chain.hip: tasks drawn from per-XCD queues, a task waits only for its own frame tile's node tiles of the
+ * layer before) for batches of at least min_frames frames (<= 0: the default threshold), 0 = one launch per layer,
+ * -1 = the default (FDNN_CHAIN / FDNN_CHAIN_MIN in the environment, else on).  Process-wide.
+ * CalculateUntilLastHiddenLayer's layer loop, src/cpp/dnn.cc:413-423, is what is being computed. */
+FDNN_API int fdnn_debug_set_chain(int mode, int min_frames);
+
+/* Measurement builds of the chained hidden-layer kernel (-DFDNN_CHAIN_CLK=1; the shipped library records nothing): with
+ * out == NULL, give the context a buffer for the phase clocks of cap_tasks tasks; with out != NULL copy the records of the
+ * launches since ([0] = tasks recorded, then from [8] ten words per task: block / task id, XCD / layer / frame tile, the
+ * wall clock, seven cycle stamps) into out[8 + 10 * cap_tasks] and start over. */
+FDNN_API int fdnn_debug_chain_clocks(fdnn_ctx *c, long long *out, int cap_tasks);
+
 /* Layer 0 alone through the PRODUCTION kernels (no taps): u8_out [n][hidden_dim].  Large batches take the
  * screened path (fused chains on the fp32 matrix pipe, a rigorous bound on |fused - unfused|, exact unfused
  * recomputation of the outputs whose table index the difference could change); *recomputed (may be NULL)
