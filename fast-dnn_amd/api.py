@@ -60,6 +60,7 @@ SIGNATURES = {
     "fdnn_model_set_l0_fma": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_set_l0_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_set_chain": (C.c_int, [C.c_int, C.c_int]),
+    "fdnn_debug_set_l0_list_cap": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_chain_clocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]),
     "fdnn_calculate": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, C.c_int, _c_f32p]),
     "fdnn_calculate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
@@ -100,6 +101,7 @@ SIGNATURES = {
     "fdnn_debug_production_acc_out": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, _c_i8p, _c_i32p, _c_f32p]),
     "fdnn_debug_forward_taps": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_i8p, _c_f32p, _c_u8p, _c_i32p, _c_i32p, _c_f32p, _c_f32p]),
     "fdnn_debug_layer0": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_u8p, C.POINTER(C.c_ulonglong)]),
+    "fdnn_debug_layer0_screen": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_u8p, _c_f32p, _c_f32p, C.POINTER(C.c_ulonglong)]),
     "fdnn_ctx_lazy_output_batch_bits": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fdnn_ctx_lazy_output_batch_bits_device": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fdnn_model_fuse_giveups": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
@@ -446,6 +448,10 @@ class QuantizedDnn:
     def setInputLayerFma(self, on: bool) -> None:
         _check(lib().fdnn_model_set_l0_fma(self.nativeDnnHandle, int(on)))
 
+    def setInputLayerListCap(self, cap: int) -> None:
+        """Tests: cap the flagged-output list of the int8-screened input layer (contexts created afterwards)."""
+        _check(lib().fdnn_debug_set_l0_list_cap(self.nativeDnnHandle, int(cap)))
+
     def setInputLayerKernel(self, kind: int) -> None:
         """0 = chosen by batch size, 1 = chain-pass kernel, 2 = 64 x 64-tile kernel, 3 = screened path where available (same bits)."""
         _check(lib().fdnn_debug_set_l0_kernel(self.nativeDnnHandle, int(kind)))
@@ -515,6 +521,18 @@ class QuantizedDnn:
         return out, int(rec.value)
 
     # -- parity taps ----------------------------------------------------------
+    def layer0Screen(self, input):
+        """(u8 [n][H], t~ [n][H], Dd [n][H], recomputed): the int8-screened input layer with what the screen saw per output."""
+        x = _f32(input)
+        H = self.hiddenDimension()
+        out = np.empty((x.shape[0], H), dtype=np.uint8)
+        t = np.empty((x.shape[0], H), dtype=np.float32)
+        dd = np.empty((x.shape[0], H), dtype=np.float32)
+        rec = C.c_ulonglong(0)
+        _check(lib().fdnn_debug_layer0_screen(self.nativeDnnHandle, x.ctypes.data_as(_c_f32p), x.shape[0], out.ctypes.data_as(_c_u8p),
+                                              t.ctypes.data_as(_c_f32p), dd.ctypes.data_as(_c_f32p), C.byref(rec)))
+        return out, t, dd, int(rec.value)
+
     def productionOutputAcc(self, input, stride: int, masks=None, probs: bool = False):
         """int32 accumulators of the output layer's PRODUCTION kernel instance for every stride-th frame
         ([ceil(n/stride)][O]); with probs=True also the call's probabilities."""

@@ -53,6 +53,7 @@ struct fdnn_model {
   int l0_jc = 0, l0_j_pad = 0, l0_h_ld = 0;
   int l0_fma = 0;
   int l0_kernel = 0;  // fdnn_debug_set_l0_kernel
+  int l0_list_cap = 0;  // fdnn_debug_set_l0_list_cap: > 0 caps the flagged-output list of contexts created afterwards (tests)
   std::mutex mu;
   std::vector<fdnn_ctx *> pool;  // idle contexts owned by the model (fdnn_calculate*)
   struct fdnn_server *batcher = nullptr;  // fdnn_model_enable_batcher: fdnn_calculate goes through it
@@ -100,6 +101,7 @@ struct fdnn_ctx {
   uint32_t *d_chain_done = nullptr;  // [frame tiles][layers of the chain] node tiles finished; zero between launches
   long long *d_chain_clk = nullptr;  // measurement builds only: per-task phase clocks
   int chain_clk_cap = 0;
+  float *d_l0_dbg_t = nullptr, *d_l0_dbg_dd = nullptr;  // fdnn_debug_layer0_screen only: the int8 screening's t~ and Dd per output
   uint64_t *d_mask_bits = nullptr;  // [n][ceil(O/64)] the batched lazy call's mask as bits (launch_mask_pack)
   float *d_comp = nullptr;          // host lazy batches: compacted result rows (allocated on first use)
   size_t comp_floats = 0;

@@ -48,6 +48,10 @@ struct L0Params {
   uint32_t *glist_count;  // [2]: entries appended; tiles that overflowed into the whole-tile path.  Zeroed by the pre-pass
   int glist_cap;
   const uint32_t *luthalf;  // [kLut2Size (+pad)] the half-step table, 4 bytes per entry: table byte + the 'same byte across the boundary' gate
+  // parity tests only (fdnn_debug_layer0_screen; null in production): what the int8 screening saw per output, [n][H] each --
+  // t~ = 100 lin~ and the half-width Dd of the interval it vouches for; |100 lin_ref - t~| <= Dd is the bound's claim
+  float *dbg_t;
+  float *dbg_dd;
 };
 constexpr int kL0ScreenCap = 4096;  // listed outputs per tile (25 %); a tile that overflows is recomputed whole
 void launch_l0(const L0Params &p, hipStream_t s);

@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(THREADS) void l0_fix_list_kernel(L0Params p, int ti
     const uint32_t o = base + (tid / LPO);
     const bool valid = o < total;
     const uint2 ent = valid ? p.glist[o] : make_uint2(0u, 0u);
-    fix_one_output<NB, LPO>(p, sh_s, sc_s, tr_w, static_cast<int>(ent.x), static_cast<int>(ent.y), valid && static_cast<int>(ent.x) < p.n && static_cast<int>(ent.y) < p.H, c, quads);
+    fix_one_output<NB, LPO>(p, sh_s, sc_s, tr_w, static_cast<int>(ent.x), static_cast<int>(ent.y), valid && ent.x < static_cast<uint32_t>(p.n) && ent.y < static_cast<uint32_t>(p.H), c, quads);
   }
   if (any_overflow) {
     const int node_tiles = (p.H + TN - 1) / TN;

@@ -505,6 +505,11 @@ __global__ __launch_bounds__(256 * WN, 3 - WN) void l0_split_kernel(L0Params p, 
         const float m = fmaxf(fmaxf(fabsf(e), gate), fabsf(t) - 641.0f);
         const bool flag = !(m > Dd) | !(fabsf(t) < 1.0e9f);
         scr_mask |= flag ? (1u << (16 * s + r)) : 0u;
+        if (p.dbg_t != nullptr && ((valid >> (16 * s + r)) & 1u)) {  // (uniform pointer test; tests only)
+          const size_t o = static_cast<size_t>(f0 + row) * p.H + (n0 + wn * 64 + s * 32 + l32);
+          p.dbg_t[o] = t;
+          p.dbg_dd[o] = Dd;
+        }
       }
     }
   }
@@ -551,8 +556,18 @@ __global__ __launch_bounds__(256 * WN, 3 - WN) void l0_split_kernel(L0Params p, 
     if (tid == 0) {
       uint32_t gb = 0xffffffffu;
       if (cnt != 0 && cnt <= static_cast<uint32_t>(kL0ScreenCap)) {
-        gb = atomicAdd(p.glist_count, cnt);
-        if (gb + cnt > static_cast<uint32_t>(p.glist_cap)) gb = 0xffffffffu;  // (the list is full: the fix kernel clamps its walk to the capacity)
+        // reserve [gb, gb + cnt) only if it fits: a failed reservation must not advance the counter (an add-then-test left
+        // [gb, cap) reserved and never written, yet walked by the fix kernel: round-4 advisor finding)
+        uint32_t seen = __hip_atomic_load(p.glist_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+          if (seen + cnt > static_cast<uint32_t>(p.glist_cap)) break;  // the list is full: this tile takes the whole-tile path
+          const uint32_t prev = atomicCAS(p.glist_count, seen, seen + cnt);
+          if (prev == seen) {
+            gb = seen;
+            break;
+          }
+          seen = prev;
+        }
       }
       if (cnt != 0 && gb == 0xffffffffu) {  // too many for either list: the fix kernel recomputes the whole tile
         p.scr_count[by * (p.h_ld / 128) + (n0 >> 7)] = cnt;  // (the whole-tile path works on 128 x 128 tiles)

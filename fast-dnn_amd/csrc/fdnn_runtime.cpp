@@ -166,6 +166,8 @@ void destroy_ctx(fdnn_ctx *c) {
   hipFree(c->d_chain_ctl);
   hipFree(c->d_chain_done);
   hipFree(c->d_chain_clk);
+  hipFree(c->d_l0_dbg_t);
+  hipFree(c->d_l0_dbg_dd);
   if (c->h_mask_pin) hipHostFree(c->h_mask_pin);
   if (c->h_out_pin) hipHostFree(c->h_out_pin);
   if (c->done) hipEventDestroy(c->done);
@@ -207,8 +209,10 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
     alloc(reinterpret_cast<void **>(&c->d_xd), fdnn::l0_split_plane_bytes(h.in_dim, c->xt_ld));
     alloc(reinterpret_cast<void **>(&c->d_xstat), sizeof(float) * 3 * size_t(c->xt_ld));
     c->glist_cap = int(std::min<size_t>(size_t(c->xt_ld) * size_t(m->l0_h_ld) / 16, size_t(1) << 26));  // 6 % of the outputs
+    if (m->l0_list_cap > 0) c->glist_cap = std::min(c->glist_cap, m->l0_list_cap);  // (tests: fdnn_debug_set_l0_list_cap)
     alloc(reinterpret_cast<void **>(&c->d_glist), sizeof(uint2) * size_t(c->glist_cap));
     alloc(reinterpret_cast<void **>(&c->d_glist_count), sizeof(uint32_t) * 2);
+    if (e == hipSuccess) e = hipMemset(c->d_glist, 0, sizeof(uint2) * size_t(c->glist_cap));
     if (e == hipSuccess) e = hipMemset(c->d_glist_count, 0, sizeof(uint32_t) * 2);
   }
   if (fdnn::l0_chain_node_tile() == 128)  // the 64-node tile keeps its partial sums in registers
@@ -363,6 +367,8 @@ void run_layer0(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) 
   l0.glist = c->d_glist;
   l0.glist_count = c->d_glist_count;
   l0.glist_cap = c->glist_cap;
+  l0.dbg_t = c->d_l0_dbg_t;
+  l0.dbg_dd = c->d_l0_dbg_dd;
   l0.j_pad = m->l0_j_pad;
   l0.jc = m->l0_jc;
   l0.n_ld = c->xt_ld;
@@ -923,6 +929,15 @@ int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind) {
   return FDNN_OK;
 }
 
+int fdnn_debug_set_l0_list_cap(fdnn_model *m, int cap) {
+  if (!m || cap < 0) return fail(FDNN_E_ARG, "bad argument");
+  std::lock_guard<std::mutex> lk(m->mu);
+  for (fdnn_ctx *c : m->pool) destroy_ctx(c);  // pooled contexts carry the old capacity
+  m->pool.clear();
+  m->l0_list_cap = cap;
+  return FDNN_OK;
+}
+
 int fdnn_debug_set_chain(int mode, int min_frames) {
   if (mode < -1 || mode > 1) return fail(FDNN_E_ARG, "chain mode must be -1, 0 or 1");
   fdnn::qchain_set_mode(mode, min_frames);
@@ -1333,6 +1348,45 @@ int fdnn_debug_layer0(fdnn_model *m, const float *x, int n, uint8_t *u8_out, uns
   if (e == hipSuccess) e = hipMemcpy(after, m->d_l0_stats, sizeof(after), hipMemcpyDeviceToHost);
   fdnn_ctx_free(c);
   if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("layer 0: ") + hipGetErrorString(e));
+  for (int f = 0; f < n; ++f)
+    for (int i = 0; i < h.hidden; ++i) u8_out[size_t(f) * h.hidden + i] = uint8_t(tmp[size_t(f) * act_ld + i]) ^ 0x80;
+  if (recomputed) *recomputed = after[1] - before[1];
+  return FDNN_OK;
+}
+
+int fdnn_debug_layer0_screen(fdnn_model *m, const float *x, int n, uint8_t *u8_out, float *t_out, float *dd_out, unsigned long long *recomputed) {
+  if (!m || !x || !u8_out || !t_out || !dd_out || n <= 0) return fail(FDNN_E_ARG, "bad argument");
+  if (!m->d_w0d) return fail(FDNN_E_STATE, "this model's input layer has no int8 screening (input width outside 64..496)");
+  DeviceGuard g(m->device);
+  const BlobHeader &h = m->hm.hdr;
+  fdnn_ctx *c = nullptr;
+  int rc = make_ctx(m, n, &c);
+  if (rc) return rc;
+  const size_t outs = size_t(n) * h.hidden;
+  unsigned long long before[2] = {0, 0}, after[2] = {0, 0};
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_l0_dbg_t), outs * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_l0_dbg_dd), outs * sizeof(float));
+  if (e == hipSuccess) e = hipMemset(c->d_l0_dbg_t, 0xff, outs * sizeof(float));  // NaN: an output the screening kernel did not visit
+  if (e == hipSuccess) e = hipMemset(c->d_l0_dbg_dd, 0xff, outs * sizeof(float));
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(before, m->d_l0_stats, sizeof(before), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x, sizeof(float) * size_t(n) * h.in_dim, hipMemcpyHostToDevice, c->stream);
+  const int kernel_before = m->l0_kernel;
+  if (e == hipSuccess) {
+    if (m->l0_kernel == 0) m->l0_kernel = 4;  // the int8 screening whatever the batch size
+    run_layer0(c, c->d_x, c->stream, nullptr);
+    m->l0_kernel = kernel_before;
+    e = hipGetLastError();
+  }
+  const size_t act_ld = size_t(c->act_ld);
+  std::vector<int8_t> tmp(size_t(n) * act_ld);
+  if (e == hipSuccess) e = hipMemcpyAsync(tmp.data(), c->d_act[0], tmp.size(), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(t_out, c->d_l0_dbg_t, outs * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dd_out, c->d_l0_dbg_dd, outs * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = hipMemcpy(after, m->d_l0_stats, sizeof(after), hipMemcpyDeviceToHost);
+  fdnn_ctx_free(c);
+  if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("layer 0 (screen debug): ") + hipGetErrorString(e));
   for (int f = 0; f < n; ++f)
     for (int i = 0; i < h.hidden; ++i) u8_out[size_t(f) * h.hidden + i] = uint8_t(tmp[size_t(f) * act_ld + i]) ^ 0x80;
   if (recomputed) *recomputed = after[1] - before[1];

@@ -258,6 +258,11 @@ FDNN_API int fdnn_debug_frame_chunks(int n, int *chunks, int cap);
  * available (batches of 2048 frames and more, no taps). */
 FDNN_API int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind);
 
+/* Tests only: cap the per-launch list of flagged layer-0 outputs (int8 screening) of contexts created AFTER the call at
+ * `cap` entries (0 = the default, 1/16 of the outputs), so that a small batch overflows it: tiles that no longer fit take
+ * the whole-tile recomputation, results unchanged.  Drops the model's pooled contexts.  InputActivations, dnn.cc:219-247. */
+FDNN_API int fdnn_debug_set_l0_list_cap(fdnn_model *m, int cap);
+
 /* How the int8 hidden layers run (tests / measurements only; results are bit-identical): mode 1 = as ONE persistent
  * launch (fdnn_chain.hip: tasks drawn from per-XCD queues, a task waits only for its own frame tile's node tiles of the
  * layer before) for batches of at least min_frames frames (<= 0: the default threshold), 0 = one launch per layer,
@@ -276,6 +281,14 @@ FDNN_API int fdnn_debug_chain_clocks(fdnn_ctx *c, long long *out, int cap_tasks)
  * recomputation of the outputs whose table index the difference could change); *recomputed (may be NULL)
  * receives how many outputs of this call were recomputed.  Tests compare u8_out with the oracle bit for bit. */
 FDNN_API int fdnn_debug_layer0(fdnn_model *m, const float *x, int n, uint8_t *u8_out, unsigned long long *recomputed);
+
+/* The int8 screening of the input layer, opened up for the parity tests: besides u8_out [n][hidden_dim] (as
+ * fdnn_debug_layer0, int8-screened path at any batch size) t_out / dd_out [n][hidden_dim] receive what the screening kernel
+ * computed per output -- t~ = 100 lin~ from the exact digit products, and Dd, the half-width its error bound vouches for
+ * (fdnn_l0s.hip).  The bound's claim is |100 lin_ref - t~| <= Dd for the reference's lin (dnn.cc:219-264); the tests assert
+ * it on every output and report the slack max |100 lin_ref - t~| / Dd.  Needs an input width of 64 .. 496. */
+FDNN_API int fdnn_debug_layer0_screen(fdnn_model *m, const float *x, int n, uint8_t *u8_out, float *t_out, float *dd_out,
+                                      unsigned long long *recomputed);
 
 /* Fused soft-max health counter.  Large dense / batched-lazy calls scale their soft-max inside the output kernel: the
  * node tiles of a frame tile exchange row sums and wait for one another (bounded).  Within a process the library chains
