@@ -64,6 +64,9 @@ SIGNATURES = {
     "fdnn_debug_chain_clocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]),
     "fdnn_calculate": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, C.c_int, _c_f32p]),
     "fdnn_calculate_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "fdnn_calculate_lazy": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, _c_i8p, _c_f32p]),
+    "fdnn_calculate_lazy_bits": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, C.POINTER(C.c_uint64), _c_f32p]),
+    "fdnn_calculate_lazy_bits_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "fdnn_ctx_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "fdnn_ctx_free": (None, [C.c_void_p]),
     "fdnn_ctx_frame_count": (C.c_int, [C.c_void_p]),
@@ -129,7 +132,8 @@ SIGNATURES = {
 JNI_SYMBOLS = [
     "Java_suskun_nn_QuantizedDnn_" + n
     for n in ("initialize", "inputDimension", "outputDimension", "calculate", "getContext", "calculateUntilOutput",
-              "calculateLazy", "deleteLazyContext", "delete", "layerDimension", "layerCount")
+              "calculateLazy", "deleteLazyContext", "delete", "layerDimension", "layerCount",
+              "calculateLazyBatch")  # (the last one: an extension)
 ]
 
 
@@ -473,6 +477,33 @@ class QuantizedDnn:
     def calculate_device(self, d_x: int, n: int, d_out: int, stream: int = 0) -> None:
         """Device-resident form: raw device pointers (e.g. ``tensor.data_ptr()``), enqueued on ``stream``."""
         _check(lib().fdnn_calculate_device(self.nativeDnnHandle, C.c_void_p(d_x), n, C.c_void_p(d_out), C.c_void_p(stream)))
+
+    def calculateLazy(self, input, masks=None, bits=None, out=None) -> np.ndarray:
+        """One-call lazy scoring: hidden layers + masked output layer for every frame of ``input`` (LazyContext's
+        calculateUntilOutput + calculateForOutputNodes per frame, QuantizedDnn.java:72-107, in one native call).
+        ``masks`` [n][outputDimension] bytes (non-zero = active) or ``bits`` [n][ceil(O / 64)] uint64."""
+        x = _f32(input)
+        n, O = x.shape[0], self.outputDimension()
+        if n and x.shape[1] != self.inputDimension():
+            raise ValueError(f"input vector size {x.shape[1]} must be equal with network input size {self.inputDimension()}")
+        if out is None:
+            out = np.empty((n, O), dtype=np.float32)
+        if bits is not None:
+            b = np.ascontiguousarray(bits, dtype=np.uint64)
+            if b.shape != (n, (O + 63) // 64):
+                raise ValueError("bits must be [frames][ceil(outputDimension / 64)] uint64")
+            _check(lib().fdnn_calculate_lazy_bits(self.nativeDnnHandle, x.ctypes.data_as(_c_f32p), n, x.shape[1] if n else self.inputDimension(),
+                                                  b.ctypes.data_as(C.POINTER(C.c_uint64)), out.ctypes.data_as(_c_f32p)))
+        else:
+            m = np.ascontiguousarray(masks, dtype=np.int8)
+            if m.shape != (n, O):
+                raise ValueError("masks must be [frames][outputDimension]")
+            _check(lib().fdnn_calculate_lazy(self.nativeDnnHandle, x.ctypes.data_as(_c_f32p), n, x.shape[1] if n else self.inputDimension(),
+                                             m.ctypes.data_as(_c_i8p), out.ctypes.data_as(_c_f32p)))
+        return out
+
+    def calculate_lazy_bits_device(self, d_x: int, n: int, d_bits: int, d_out: int, stream: int = 0) -> None:
+        _check(lib().fdnn_calculate_lazy_bits_device(self.nativeDnnHandle, C.c_void_p(d_x), n, C.c_void_p(d_bits), C.c_void_p(d_out), C.c_void_p(stream)))
 
     # -- lazy path ----------------------------------------------------------
     def getNewLazyContext(self, inputVectorCount: int, batchSize: int = 8) -> LazyContext:

@@ -168,6 +168,39 @@ jfloatArray Java_suskun_nn_QuantizedDnn_calculateLazy(JNIEnv *env, jobject, jlon
   return to_java(env, out.data(), out.size());
 }
 
+// EXTENSION (not in the reference's header): the lazy contract for a whole utterance in one native call --
+//   private native float[] calculateLazyBatch(long handle, float[] flatInput, int n, int dim, byte[] flatMasks);
+// flatMasks = n x outputDimension bytes, row-major, non-zero = active (the per-frame calculateLazy's mask, jni_dnn.cc:97-117,
+// n times).  Returns n x outputDimension floats.  What LazyContext.calculateUntilOutput + n x calculateForOutputNodes do
+// (QuantizedDnn.java:72-107) without the per-frame JNI round trips (README.md:45).  Uses the same nine JNI services.
+jfloatArray Java_suskun_nn_QuantizedDnn_calculateLazyBatch(JNIEnv *env, jobject, jlong handle, jfloatArray flat, jint n, jint dim,
+                                                           jbyteArray masks) {
+  fdnn_model *m = reinterpret_cast<fdnn_model *>(handle);
+  const size_t O = static_cast<size_t>(fdnn_model_output_dim(m));
+  const size_t len = static_cast<size_t>(n < 0 ? 0 : n) * O;
+  if (n < 0 || len > static_cast<size_t>(INT32_MAX)) {
+    throw_status(env, FDNN_E_ARG, "frames x output nodes does not fit a Java float[] (2^31 - 1 elements): score the batch in pieces");
+    return nullptr;
+  }
+  if (static_cast<size_t>(slot<GetArrayLengthFn>(env, FDNN_JNI_GetArrayLength)(env, masks)) != len) {
+    throw_status(env, FDNN_E_ARG, "mask array length must equal frames x output nodes");
+    return nullptr;
+  }
+  jfloat *elements = slot<GetFloatArrayElementsFn>(env, FDNN_JNI_GetFloatArrayElements)(env, flat, nullptr);
+  jbyte *bytes = slot<GetByteArrayElementsFn>(env, FDNN_JNI_GetByteArrayElements)(env, masks, nullptr);
+  float *out = t_scratch.get(len);
+  int rc = out ? fdnn_calculate_lazy(m, elements, n, dim, bytes, out) : FDNN_E_NOMEM;
+  slot<ReleaseByteArrayElementsFn>(env, FDNN_JNI_ReleaseByteArrayElements)(env, masks, bytes, FDNN_JNI_ABORT);
+  slot<ReleaseFloatArrayElementsFn>(env, FDNN_JNI_ReleaseFloatArrayElements)(env, flat, elements, FDNN_JNI_ABORT);
+  jfloatArray result = nullptr;
+  if (rc)
+    throw_status(env, rc, out ? nullptr : "out of host memory for the result block");
+  else
+    result = to_java(env, out, len);
+  if (len * sizeof(float) > scratch_keep_bytes()) t_scratch.release();
+  return result;
+}
+
 void Java_suskun_nn_QuantizedDnn_deleteLazyContext(JNIEnv *, jobject, jlong handle) {
   fdnn_ctx_free(reinterpret_cast<fdnn_ctx *>(handle));
 }

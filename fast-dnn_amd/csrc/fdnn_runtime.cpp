@@ -7,6 +7,7 @@
 // fdnn_calculate draws contexts from a per-model pool so that concurrent callers
 // (MultiThreadedStressTest.java:48-69) never share scratch.
 #include <hip/hip_runtime.h>
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1026,6 +1027,27 @@ int fdnn_ctx_lazy_output_batch_device(fdnn_ctx *c, int first, int count, const i
 
 static int lazy_copy_out(fdnn_ctx *c, int count, const uint64_t *d_bits, const uint64_t *bits, float *out, hipStream_t s);
 
+// masks [count][O] bytes (non-zero = active, dnn.cc:361) -> bits [count][ceil(O / 64)], 16 bytes per step
+static void pack_mask_rows(const int8_t *masks, int count, size_t O, uint64_t *bits) {
+  const size_t wpr = (O + 63) / 64;
+  const __m128i zero = _mm_setzero_si128();
+  for (int f = 0; f < count; ++f) {
+    const int8_t *mrow = masks + size_t(f) * O;
+    uint64_t *brow = bits + size_t(f) * wpr;
+    size_t k = 0;
+    for (size_t w = 0; w < wpr; ++w) {
+      uint64_t word = 0;
+      for (int q = 0; q < 4 && k + 16 <= O; ++q, k += 16) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(mrow + k));
+        word |= uint64_t(uint32_t(~_mm_movemask_epi8(_mm_cmpeq_epi8(v, zero))) & 0xffffu) << (16 * q);
+      }
+      const size_t base = 64 * w;
+      for (; k < O && k < base + 64; ++k) word |= uint64_t(mrow[k] != 0) << (k - base);
+      brow[w] = word;
+    }
+  }
+}
+
 int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *masks, float *out) {
   if (!c || !out || !masks) return fail(FDNN_E_ARG, "null argument");
   if (c->last < 0) return fail(FDNN_E_STATE, "calculateLazy before calculateUntilOutput");
@@ -1054,11 +1076,7 @@ int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *
     // by the pack kernel (a large batch's output kernel has run it already)
     const size_t wpr = (O + 63) / 64;
     std::vector<uint64_t> hb(size_t(count) * wpr, 0);
-    for (int f = 0; f < count; ++f) {
-      const int8_t *mrow = masks + size_t(f) * O;
-      uint64_t *brow = hb.data() + size_t(f) * wpr;
-      for (size_t k = 0; k < O; ++k) brow[k >> 6] |= uint64_t(mrow[k] != 0) << (k & 63);
-    }
+    pack_mask_rows(masks, count, O, hb.data());
     fdnn::launch_mask_pack(c->d_mask, c->d_mask_bits, count, int(O), c->stream);
     rc = lazy_copy_out(c, count, c->d_mask_bits, hb.data(), out, c->stream);
   }
@@ -1217,6 +1235,76 @@ int fdnn_calculate(fdnn_model *m, const float *x, int n, int dim, int batch_hint
   if (!x || !out) return fail(FDNN_E_ARG, "null buffer");
   if (m->group) return fdnn_group_calculate(m->group, x, n, dim, batch_hint, out);  // sharded over the node's devices
   return fdnn::calculate_on_one_device(m, x, n, dim, batch_hint, out);
+}
+
+// One-call lazy scoring: hidden layers + masked output + compacted return in ONE call and ONE stream synchronisation
+// (a LazyContext costs two calls and two synchronisations per utterance: calculateUntilOutput, then the masked rows).
+int fdnn_calculate_lazy_bits(fdnn_model *m, const float *x, int n, int dim, const uint64_t *bits, float *out) {
+  if (!m || n < 0) return fail(FDNN_E_ARG, "bad argument");
+  if (n == 0) return FDNN_OK;
+  if (!x || !out || !bits) return fail(FDNN_E_ARG, "null buffer");
+  const BlobHeader &h = m->hm.hdr;
+  if (dim != h.in_dim)
+    return fail(FDNN_E_ARG, "input vector size " + std::to_string(dim) + " must be equal with network input size " + std::to_string(h.in_dim));
+  DeviceGuard g(m->device);
+  const size_t wpr = (size_t(h.out_dim) + 63) / 64;
+  int rc = FDNN_OK;
+  for (int first = 0; first < n && !rc; first += fdnn::kChunkFrames) {  // (very large calls: chunk by chunk, as the dense call)
+    const int cnt = std::min(fdnn::kChunkFrames, n - first);
+    fdnn_ctx *c = nullptr;
+    rc = acquire_ctx(m, cnt, &c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    hipError_t e = ctx_enter(c, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x + size_t(first) * dim, sizeof(float) * size_t(cnt) * dim, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_mask_bits, bits + size_t(first) * wpr, sizeof(uint64_t) * size_t(cnt) * wpr, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) {
+      rc = run_hidden(c, c->d_x, s, nullptr);
+      if (!rc) rc = run_output(c, 0, cnt, nullptr, c->d_out, s, nullptr, nullptr, nullptr, nullptr, c->d_mask_bits);
+      if (!rc) rc = lazy_copy_out(c, cnt, c->d_mask_bits, bits + size_t(first) * wpr, out + size_t(first) * h.out_dim, s);
+      if (rc) hipStreamSynchronize(s);
+    }
+    release_ctx(c, s);
+    if (!rc && e != hipSuccess) rc = fail(FDNN_E_DEVICE, std::string("fdnn_calculate_lazy_bits: ") + hipGetErrorString(e));
+  }
+  return rc;
+}
+
+int fdnn_calculate_lazy(fdnn_model *m, const float *x, int n, int dim, const int8_t *masks, float *out) {
+  if (!m || n < 0) return fail(FDNN_E_ARG, "bad argument");
+  if (n == 0) return FDNN_OK;
+  if (!masks) return fail(FDNN_E_ARG, "null buffer");
+  const size_t O = size_t(m->hm.hdr.out_dim), wpr = (O + 63) / 64;
+  std::vector<uint64_t> hb(size_t(n) * wpr);
+  pack_mask_rows(masks, n, O, hb.data());
+  return fdnn_calculate_lazy_bits(m, x, n, dim, hb.data(), out);
+}
+
+int fdnn_calculate_lazy_bits_device(fdnn_model *m, const float *d_x, int n, const uint64_t *d_bits, float *d_out, void *stream) {
+  if (!m || n < 0) return fail(FDNN_E_ARG, "bad argument");
+  if (n == 0) return FDNN_OK;
+  if (!d_x || !d_out || !d_bits) return fail(FDNN_E_ARG, "null buffer");
+  DeviceGuard g(m->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  fdnn_ctx *c = nullptr;
+  const auto chunks = fdnn::frame_chunks(n);
+  int cap = 0;
+  for (const auto &ch : chunks) cap = std::max(cap, ch.second);
+  int rc = acquire_ctx(m, cap, &c);
+  if (rc) return rc;
+  const hipError_t e = ctx_enter(c, s);
+  if (e == hipSuccess) {
+    const size_t D = size_t(m->hm.hdr.in_dim), O = size_t(m->hm.hdr.out_dim), wpr = (O + 63) / 64;
+    for (const auto &ch : chunks) {
+      c->n = ch.second;
+      rc = run_hidden(c, d_x + size_t(ch.first) * D, s, nullptr);
+      if (!rc) rc = run_output(c, 0, ch.second, nullptr, d_out + size_t(ch.first) * O, s, nullptr, nullptr, nullptr, nullptr, d_bits + size_t(ch.first) * wpr);
+      if (rc) break;
+    }
+  }
+  release_ctx(c, s);
+  if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("fdnn_calculate_lazy_bits_device: ") + hipGetErrorString(e));
+  return rc;
 }
 
 // ---------------------------------------------------------------- taps

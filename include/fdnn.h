@@ -109,6 +109,18 @@ FDNN_API int fdnn_calculate(fdnn_model *m, const float *x, int n, int dim, int b
  * hipStream_t; NULL = default stream) and NOT synchronized. */
 FDNN_API int fdnn_calculate_device(fdnn_model *m, const float *d_x, int n, float *d_out, void *stream);
 
+/* One-call lazy scoring: CalculateUntilLastHiddenLayer (dnn.cc:402-424) + LazyOutputActivations
+ * (dnn.cc:355-392) for every frame of the call, in one call and one stream synchronisation -- what a LazyContext does in
+ * two calls per utterance (QuantizedDnn.java:72-107), without the per-frame JNI round trips README.md:45 complains about.
+ *   fdnn_calculate_lazy       masks [n][output_dim] bytes, non-zero = active (the JNI contract's byte masks)
+ *   fdnn_calculate_lazy_bits  bits [n][ceil(output_dim / 64)] 64-bit words, bit b of word w = node 64 w + b
+ * out [n][output_dim]: active nodes their probability, inactive nodes 1 / total (dnn.cc:366-369, :389).  Host callers get
+ * their rows back COMPACTED over PCIe (active probabilities + one value per frame) and rebuilt in `out`.
+ * The _device form works on device-resident buffers, enqueued on `stream`, not synchronised. */
+FDNN_API int fdnn_calculate_lazy(fdnn_model *m, const float *x, int n, int dim, const int8_t *masks, float *out);
+FDNN_API int fdnn_calculate_lazy_bits(fdnn_model *m, const float *x, int n, int dim, const uint64_t *bits, float *out);
+FDNN_API int fdnn_calculate_lazy_bits_device(fdnn_model *m, const float *d_x, int n, const uint64_t *d_bits, float *d_out, void *stream);
+
 /* ------------------------------------------------------------------ contexts / lazy path
  * fdnn_ctx_create <- getContext / jni_dnn.cc:64-77 (CalculationContext ctor,
  *   dnn.cc:194-215): device scratch for n frames. */

@@ -74,6 +74,9 @@ FDNN_JNIEXPORT void Java_suskun_nn_QuantizedDnn_calculateUntilOutput(JNIEnv *, j
 /* native float[] calculateLazy(long, int, byte[])                     jni_dnn.cc:97-117 */
 FDNN_JNIEXPORT jfloatArray Java_suskun_nn_QuantizedDnn_calculateLazy(JNIEnv *, jobject, jlong, jint, jbyteArray);
 /* native void deleteLazyContext(long)                                 jni_dnn.cc:119-126 */
+/* EXTENSION, not in suskun_nn_QuantizedDnn.h: the lazy contract for n frames in one call --
+ * private native float[] calculateLazyBatch(long handle, float[] flatInput, int n, int dim, byte[] flatMasks); */
+FDNN_JNIEXPORT jfloatArray Java_suskun_nn_QuantizedDnn_calculateLazyBatch(JNIEnv *, jobject, jlong, jfloatArray, jint, jint, jbyteArray);
 FDNN_JNIEXPORT void Java_suskun_nn_QuantizedDnn_deleteLazyContext(JNIEnv *, jobject, jlong);
 /* native void delete(long)                                            jni_dnn.cc:128-133 */
 FDNN_JNIEXPORT void Java_suskun_nn_QuantizedDnn_delete(JNIEnv *, jobject, jlong);

@@ -144,6 +144,7 @@ class JavaQuantizedDnn:
             ("calculateUntilOutput", None, [vp, vp, cl, vp]), ("calculateLazy", vp, [vp, vp, cl, ci, vp]),
             ("deleteLazyContext", None, [vp, vp, cl]), ("delete", None, [vp, vp, cl]),
             ("layerDimension", ci, [vp, vp, cl, ci]), ("layerCount", ci, [vp, vp, cl]),
+            ("calculateLazyBatch", vp, [vp, vp, cl, vp, ci, ci, vp]),  # extension (include/fdnn_jni.h)
         ]:
             fn = getattr(lib, P + name)
             fn.restype, fn.argtypes = res, args
@@ -191,6 +192,17 @@ class JavaQuantizedDnn:
         jarr = self.jvm.new_object(flat)
         res = self._call("calculate", self.handle, jarr, len(input2d), len(input2d[0]), batchSize)
         return self.jvm.get(res).reshape(len(input2d), self.outputDim), flat  # toMatrix :180-186
+
+    def calculateLazyBatch(self, input2d, masks2d):
+        """The extension's Java side: flatten frames and masks row-major, one native call, unflatten."""
+        if len(input2d) == 0:
+            return np.zeros((0, 0), dtype=np.float32)
+        if len(input2d[0]) != self.inputDim:
+            raise ValueError("Input vector size %d must be equal with network input size %d" % (len(input2d[0]), self.inputDim))
+        flat = np.ascontiguousarray(input2d, dtype=np.float32).reshape(-1).copy()
+        fm = np.ascontiguousarray(masks2d, dtype=np.int8).reshape(-1).copy()
+        res = self._call("calculateLazyBatch", self.handle, self.jvm.new_object(flat), len(input2d), len(input2d[0]), self.jvm.new_object(fm))
+        return self.jvm.get(res).reshape(len(input2d), self.outputDim)
 
     class LazyContext:
         def __init__(self, dnn, handle, n):

@@ -50,6 +50,12 @@ def test_java_facade_sequence(tiny_model_path):
         ctx.calculateForOutputNodes(masks[0])  # frame 100 of 100
     assert e.value.cls == "java/lang/IllegalArgumentException"
     ctx.delete()
+    # the one-call extension returns the same rows as the per-frame protocol (bit for bit: same kernels per frame)
+    batch = dnn.calculateLazyBatch(g["x16"], masks)
+    assert np.abs(batch - want).max() <= 2e-6 and np.array_equal(batch, rows)
+    with pytest.raises(JavaException) as e:
+        dnn._call("calculateLazyBatch", dnn.handle, jvm.new_object(g["x16"].reshape(-1).copy()), 100, 432, jvm.new_object(np.zeros(5, np.int8)))
+    assert e.value.cls == "java/lang/IllegalArgumentException"
     dnn.delete()
     assert jvm.leaks() == 0
     assert jvm.stats["get_float"] == jvm.stats["release_float"]
