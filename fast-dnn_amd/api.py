@@ -60,6 +60,7 @@ SIGNATURES = {
     "fdnn_model_set_l0_fma": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_set_l0_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_set_chain": (C.c_int, [C.c_int, C.c_int]),
+    "fdnn_device_shared": (C.c_int, [C.c_int]),
     "fdnn_debug_set_l0_list_cap": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_chain_clocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]),
     "fdnn_calculate": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, C.c_int, _c_f32p]),
@@ -191,6 +192,14 @@ def _f32(a) -> np.ndarray:
 
 def device_count() -> int:
     return int(lib().fdnn_device_count())
+
+
+def device_shared(device: int = 0) -> bool:
+    """True when another process held the GPU's marker first: this process runs the unfused soft-max (fdnn_device_shared)."""
+    r = int(lib().fdnn_device_shared(int(device)))
+    if r < 0:
+        _check(r)
+    return r == 1
 
 
 def set_chain(mode: int, min_frames: int = 0) -> None:

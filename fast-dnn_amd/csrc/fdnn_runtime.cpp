@@ -8,6 +8,10 @@
 // (MultiThreadedStressTest.java:48-69) never share scratch.
 #include <hip/hip_runtime.h>
 #include <emmintrin.h>
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -459,6 +463,49 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
 // over frames [first, first+count) of the context's last hidden activations.
 // Rows [first+count, first+n_pad) are read by the GEMM as padding frames; the
 // activation buffers carry one tile of slack rows for that.
+// Two PROCESSES on one GPU.  Inside a process the fused soft-max launches of a device are chained (FuseChain below); two
+// processes cannot be, and their fused kernels' workgroups can hold each other's CUs while every one of them sits out its
+// bounded wait (correct results, ~100 x the latency).  So the first process to load a model on a device takes an advisory
+// lock on /dev/shm/fdnn-gpu-<pci bus id> and keeps it for its lifetime; a process that finds the lock taken runs the
+// UNFUSED output path (output kernel + scale pass: nothing in it waits for another workgroup) and says so once on stderr.
+// The chained hidden-layer kernel needs no such care: its tasks only ever wait for tasks drawn earlier (fdnn_chain.hip).
+// FDNN_FUSE_NORM=0 / 1 in the environment forces the unfused / fused path regardless.  Two containers that share a GPU but
+// not /dev/shm cannot see each other: set FDNN_FUSE_NORM=0 there.
+static int device_marker_state(int device) {  // 1 = this process owns the device's marker (or cannot tell), 0 = another process does
+  static std::mutex mu;
+  static int state[64];
+  static bool known[64];
+  std::lock_guard<std::mutex> lk(mu);
+  const int d = device & 63;
+  if (known[d]) return state[d];
+  known[d] = true;
+  state[d] = 1;
+  char bus[64] = "";
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess || !bus[0]) std::snprintf(bus, sizeof(bus), "dev%d", device);
+  for (char *q = bus; *q; ++q)
+    if (*q == ':' || *q == '/') *q = '-';
+  for (const char *dir : {"/dev/shm", "/tmp"}) {
+    const std::string path = std::string(dir) + "/fdnn-gpu-" + bus;
+    const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+    if (fd < 0) continue;
+    fchmod(fd, 0666);
+    if (flock(fd, LOCK_EX | LOCK_NB) == 0) return state[d];  // (kept open: the lock lives as long as this process)
+    close(fd);
+    state[d] = 0;
+    std::fprintf(stderr, "fast-dnn: another process is scoring on GPU %s: this one runs the unfused soft-max (fdnn_device_shared)\n", bus);
+    return state[d];
+  }
+  return state[d];
+}
+static bool process_may_fuse(int device) {
+  static const int forced = [] {
+    const char *e = std::getenv("FDNN_FUSE_NORM");
+    return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
+  }();
+  if (forced >= 0) return forced == 1;
+  return device_marker_state(device) == 1;
+}
+
 // One chain of fused soft-max launches per device (see run_output).
 struct FuseChain {
   std::mutex mu;
@@ -521,7 +568,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   g.tap_logit = taps ? taps->logits : nullptr;
   g.acc_probe = taps ? taps->acc_probe : nullptr;
   g.probe_stride = taps ? std::max(1, taps->probe_stride) : 1;
-  const bool fused = !c->no_fuse && fdnn::qgemm_fused_ok(g);  // (taps exclude it; the accumulator probe of the parity tests does not)
+  const bool fused = !c->no_fuse && process_may_fuse(m->device) && fdnn::qgemm_fused_ok(g);  // (taps exclude it; the accumulator probe of the parity tests does not)
   if (fused) {
     g.final = d_final ? d_final : d_out;
     g.fuse_s = c->d_fuse_s;
@@ -591,7 +638,7 @@ bool output_will_fuse(fdnn_ctx *c, int count, const int8_t *d_masks) {
   fdnn::QGemmParams g = prepare_qlayer(c, d, c->d_act[0], count, nullptr, true);
   g.mask = d_masks;
   if (d_masks && !g.small) g.mask_bits = c->d_mask_bits;  // (what run_output will do)
-  return fdnn::qgemm_fused_ok(g);
+  return process_may_fuse(c->m->device) && fdnn::qgemm_fused_ok(g);
 }
 
 // Device -> pageable host memory for large results (the 8000-float rows of a whole batch:
@@ -807,6 +854,7 @@ int fdnn_model_load_on(const char *path, float cutoff, int device, fdnn_model **
   }
   m->device = device;
   rc = upload_model(m);
+  if (!rc) (void)fdnn_device_shared(device);  // take (or find taken) the device's process marker now, not at the first large call
   if (rc) {
     if (m->d_blob) hipFree(m->d_blob);
     if (m->d_w0t) hipFree(m->d_w0t);
@@ -928,6 +976,12 @@ int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind) {
   if (kind < 0 || kind > 4) return fail(FDNN_E_ARG, "layer-0 kernel kind must be 0 .. 4");
   m->l0_kernel = kind;
   return FDNN_OK;
+}
+
+int fdnn_device_shared(int device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return fail(FDNN_E_ARG, "no such device");
+  return device_marker_state(device) == 1 ? 0 : 1;
 }
 
 int fdnn_debug_set_l0_list_cap(fdnn_model *m, int cap) {

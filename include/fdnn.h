@@ -302,6 +302,13 @@ FDNN_API int fdnn_debug_layer0(fdnn_model *m, const float *x, int n, uint8_t *u8
 FDNN_API int fdnn_debug_layer0_screen(fdnn_model *m, const float *x, int n, uint8_t *u8_out, float *t_out, float *dd_out,
                                       unsigned long long *recomputed);
 
+/* 1 when ANOTHER process held this GPU's marker (/dev/shm/fdnn-gpu-<pci bus id>, an advisory lock taken by the first process
+ * that asks / loads a model there) when this process first looked: this process then scales its soft-max in a separate pass
+ * instead of inside the output kernel, whose workgroups wait for one another and must not share the chip with another
+ * process's (same results).  0 = this process owns the marker, or none could be created.
+ * Negative = error.  The reference's concurrency model is threads of one process (MultiThreadedStressTest.java:48-69). */
+FDNN_API int fdnn_device_shared(int device);
+
 /* Fused soft-max health counter.  Large dense / batched-lazy calls scale their soft-max inside the output kernel: the
  * node tiles of a frame tile exchange row sums and wait for one another (bounded).  Within a process the library chains
  * those launches per device, so the wait is microseconds; a workgroup whose wait nevertheless timed out (another PROCESS
