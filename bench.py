@@ -233,21 +233,31 @@ def max_over_ranks(dist, world: int, elapsed: float, dev) -> float:
     return float(t.item())
 
 
-def rank_report(dist, world: int, rank: int, digest: str, own_frames_per_s: float, device_name: str) -> dict:
+def rank_report(dist, world: int, rank: int, digest: str, own_frames_per_s: float, device_name: str, device_key: str = "", shared: bool = False,
+                peers=None) -> dict:
     """What the driver can check about an N-rank run: how many ranks the process group really has and on which backend,
-    that every rank holds the same weight blob (sha256 of what the rank's model exports), each rank's own rate."""
+    that every rank holds the same weight blob (sha256 of what the rank's model exports), each rank's own rate, that the
+    ranks sit on DIFFERENT devices (unless --share-device), and which of the other devices rank 0's can reach peer to peer
+    (hipDeviceCanAccessPeer: the xGMI links the one-process group path copies the blob over)."""
+    grouped = dist is not None and dist.is_available() and dist.is_initialized()
     if world == 1:
-        return {"ranks": 1, "collective_backend": None, "rccl_ranks": 0, "blob_sha256": digest, "blob_sha256_all_equal": True,
-                "per_rank_frames_per_s": {"min": round(own_frames_per_s, 1), "max": round(own_frames_per_s, 1)}, "devices": [device_name]}
+        backend = dist.get_backend() if grouped else None
+        return {"ranks": 1, "collective_backend": backend, "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
+                "collective_exercised": bool(grouped), "blob_sha256": digest, "blob_sha256_all_equal": True,
+                "per_rank_frames_per_s": {"min": round(own_frames_per_s, 1), "max": round(own_frames_per_s, 1)}, "devices": [device_name],
+                "peer_access_from_rank0": peers}
     parts = [None] * world
-    dist.all_gather_object(parts, (rank, digest, own_frames_per_s, device_name))
+    dist.all_gather_object(parts, (rank, digest, own_frames_per_s, device_name, device_key))
     backend = dist.get_backend()
     rates = [p[2] for p in parts]
+    keys = [p[4] for p in parts]
+    if not shared:
+        assert len(set(keys)) == world, f"{world} ranks on {len(set(keys))} distinct device(s) {keys}: one rank per GPU, or --share-device"
     return {"ranks": dist.get_world_size(), "collective_backend": backend,
-            "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
+            "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0, "collective_exercised": True,
             "blob_sha256": parts[0][1], "blob_sha256_all_equal": len({p[1] for p in parts}) == 1,
             "per_rank_frames_per_s": {"min": round(min(rates), 1), "max": round(max(rates), 1), "all": [round(r, 1) for r in rates]},
-            "devices": [p[3] for p in parts]}
+            "devices": [p[3] for p in parts], "distinct_devices": len(set(keys)), "peer_access_from_rank0": peers}
 
 
 def stub_main(args, rank: int, world: int) -> None:
@@ -286,7 +296,7 @@ def stub_main(args, rank: int, world: int) -> None:
 
     own = timed_steps(submit, lambda: None, fence, args.warmup, args.steps)
     elapsed = max_over_ranks(dist, world, own, dev)
-    rep = rank_report(dist, world, rank, digest, n * args.steps / own, "cpu (stub)")
+    rep = rank_report(dist, world, rank, digest, n * args.steps / own, "cpu (stub)", device_key="cpu", shared=True)
     if rank == 0:
         print(json.dumps({
             "metric": "acoustic frames/sec (whole node), 7x2048->8000 nnet", "value": round(world * n * args.steps / elapsed, 1),
@@ -315,6 +325,10 @@ def main() -> None:
     ap.add_argument("--share-device", action="store_true",
                     help="every rank on device 0 (one-GPU box): weights broadcast over gloo, unfused soft-max (two processes on "
                          "one GPU must not spin on each other's workgroups, INTEGRATION.md)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1: initialise the nccl (= RCCL) process group with ONE rank and take the weights through the real broadcast + import "
+                         "path of the N > 1 runs (multi_gpu.rccl_ranks = 1, collective_exercised): proves librccl loads and device-tensor "
+                         "collectives work on this box")
     ap.add_argument("--stub-scorer", action="store_true",
                     help="no GPU: gloo, host buffers and a scorer that only fills its output -- exercises launch, rendezvous, "
                          "blob broadcast + hash, barriers, max-over-ranks timing and the JSON line (tests/test_bench_launch.py)")
@@ -360,8 +374,17 @@ def main() -> None:
         raise SystemExit(f"rank {rank}: no device {local} on this box ({torch.cuda.device_count()} visible); --share-device puts every rank on device 0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    force_coll = bool(args.force_collective) and world == 1
+    if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_coll and "MASTER_PORT" not in os.environ:
+            import socket
+
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.share_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -373,7 +396,7 @@ def main() -> None:
     model_path = os.path.join(tmp, f"fdnn_net_seed1_{args.mode}.bin")
     if rank == 0:
         F.ensure_model_file(model_path, F.NET_TOPOLOGY, seed=1, mode=args.mode)
-    dnn = load_replicated(model_path, local, rank, world, host_broadcast=args.share_device)
+    dnn = load_replicated(model_path, local, rank, world, host_broadcast=args.share_device, force_collective=force_coll)
     # what THIS rank's model holds after the broadcast, hashed on the host (compared across ranks below)
     nb = dnn.blobSize()
     held = torch.empty(nb, dtype=torch.uint8, device=dev)
@@ -434,8 +457,13 @@ def main() -> None:
     own_elapsed = timed_steps(lambda i: srv.submit_device(x.data_ptr(), n, outs[i % depth].data_ptr()), srv.drain, fence, args.warmup, args.steps)
     red_dev = torch.device("cpu") if args.share_device else dev  # gloo reduces host tensors
     elapsed = max_over_ranks(dist, world, own_elapsed, red_dev)
+    props = torch.cuda.get_device_properties(local)
+    dev_key = f"{local}:{getattr(props, 'uuid', '')}:{getattr(props, 'pci_bus_id', '')}"
+    peers = None
+    if rank == 0:
+        peers = {str(j): bool(torch.cuda.can_device_access_peer(local, j)) for j in range(torch.cuda.device_count()) if j != local}
     multi = rank_report(dist, world, rank, blob_digest, n * args.steps / own_elapsed,
-                        f"{torch.cuda.get_device_name(local)} #{local}")
+                        f"{torch.cuda.get_device_name(local)} #{local}", device_key=dev_key, shared=bool(args.share_device), peers=peers)
     multi["shared_device"] = bool(args.share_device)
     assert multi["blob_sha256_all_equal"], "ranks hold different weight blobs"
 
@@ -815,7 +843,7 @@ def main() -> None:
             res["cpu_baseline"] = cpu_baseline(model_path)
         print(json.dumps(res), flush=True)
     dnn.delete()
-    if world > 1:
+    if world > 1 or force_coll:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -61,6 +61,7 @@ SIGNATURES = {
     "fdnn_debug_set_l0_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_set_chain": (C.c_int, [C.c_int, C.c_int]),
     "fdnn_device_shared": (C.c_int, [C.c_int]),
+    "fdnn_debug_set_fuse": (C.c_int, [C.c_int]),
     "fdnn_debug_set_l0_list_cap": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_chain_clocks": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.c_int]),
     "fdnn_calculate": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, C.c_int, _c_f32p]),
@@ -200,6 +201,11 @@ def device_shared(device: int = 0) -> bool:
     if r < 0:
         _check(r)
     return r == 1
+
+
+def set_fuse(mode: int) -> None:
+    """Soft-max scale of large batches (process-wide, tests): 0 = separate pass, 1 = inside the output kernel, -1 = default."""
+    _check(lib().fdnn_debug_set_fuse(int(mode)))
 
 
 def set_chain(mode: int, min_frames: int = 0) -> None:

@@ -1112,7 +1112,7 @@ void launch_qgemm(const QGemmParams &p, hipStream_t s) {
     return;
   }
   static const int small_bk = [] {
-    const char *e = std::getenv("FDNN_SMALL_BK");
+    const char *e = FDNN_TUNE_ENV("FDNN_SMALL_BK");
     return e ? std::atoi(e) : 128;
   }();
   switch (p.frame_tile) {
@@ -1129,7 +1129,7 @@ void launch_qgemm(const QGemmParams &p, hipStream_t s) {
     // narrow tiles slower (27 vs 21 us).
     case 32: {
       static const int force_wm = [] {
-        const char *e = std::getenv("FDNN_SMALL_WM");
+        const char *e = FDNN_TUNE_ENV("FDNN_SMALL_WM");
         return e ? std::atoi(e) : 0;
       }();
       const long wgs256 = static_cast<long>(p.rows_pad / 256) * (p.n_pad / 32);
@@ -1176,7 +1176,7 @@ void launch_qgemm(const QGemmParams &p, hipStream_t s) {
 
 int qgemm_debug_flags() {
   static const int flags = [] {
-    const char *e = std::getenv("FDNN_GEMM_DEBUG");
+    const char *e = std::getenv("FDNN_GEMM_DEBUG") /* test hook: bit 4096 makes fused soft-max tiles give up (tests) */;
     return e ? std::atoi(e) : 0;
   }();
   return flags;
@@ -1184,7 +1184,7 @@ int qgemm_debug_flags() {
 
 int qgemm_frame_tile(int rows_pad, int n) {
   static const int forced = [] {
-    const char *e = std::getenv("FDNN_FRAME_TILE");
+    const char *e = FDNN_TUNE_ENV("FDNN_FRAME_TILE");
     return e ? std::atoi(e) : 0;
   }();
   if (forced == 32 || forced == 64 || forced == 128 || forced == 160 || forced == 256 || forced == 320) return forced;
@@ -1225,7 +1225,7 @@ int qgemm_frame_tile(int rows_pad, int n) {
 // 44 + 15 (scale pass) vs 40 (fused) at 1000 (a workgroup of the small kernel walks its frame tiles one after the other).
 bool qgemm_small_pick(int rows_pad, int K, int n, int fastdiv, bool output) {
   static const int small_max = [] {
-    const char *e = std::getenv("FDNN_SMALL_MAX");
+    const char *e = FDNN_TUNE_ENV("FDNN_SMALL_MAX");
     return e ? std::atoi(e) : -1;
   }();
   (void)rows_pad;
@@ -1260,7 +1260,7 @@ bool qgemm_fused_ok(const QGemmParams &p) {
 
 int qgemm_node_tile(int rows_pad, int n, bool output) {
   static const int forced = [] {
-    const char *e = std::getenv("FDNN_NODE_TILE");
+    const char *e = FDNN_TUNE_ENV("FDNN_NODE_TILE");
     return e ? std::atoi(e) : 0;
   }();
   if (forced == 128 || forced == 256) return forced;

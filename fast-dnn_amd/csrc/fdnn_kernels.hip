@@ -267,7 +267,7 @@ void launch_normalize(float *out, float *dst, const float *partial, int n, int p
   if (n <= 0) return;
   if (background) {
     static const int wgs = [] {
-      const char *e = std::getenv("FDNN_NORM_BG_WGS");
+      const char *e = FDNN_TUNE_ENV("FDNN_NORM_BG_WGS");
       return e ? std::max(1, std::atoi(e)) : 256;  // sweep, 2 steps in flight: 192-256 best (+7-8 % over one stream), 512 +4 %, 1024 +2 %
     }();
     hipLaunchKernelGGL(normalize_bg_kernel, dim3(std::min(n, wgs)), dim3(256), 0, s, out, dst, partial, n, partial_ld, rows, n_partial);

@@ -5,6 +5,22 @@
 #include <cstdint>
 #include <vector>
 
+// Run-time switches.  The DEPLOYMENT switches (FDNN_BATCHER, FDNN_DEVICES, FDNN_FUSE_NORM,
+// FDNN_GROUP_*, FDNN_JNI_KEEP_MB, FDNN_CHAIN, FDNN_CHUNK_FRAMES) are read with std::getenv.  Everything else -- tile-shape
+// overrides, thresholds and kernel choices that the sweeps under tools/ turn -- exists only in measurement builds
+// (-DFDNN_ABLATION: tools/build_variant.sh): in the shipped library FDNN_TUNE_ENV is a null pointer, the defaults are
+// constants, and the compile-time ablation branches (FDNN_GEMM_DEBUG, FDNN_L0S_DEBUG, FDNN_CHAIN_CLK, ...) cannot be set.
+#ifdef FDNN_ABLATION
+#include <cstdlib>
+#define FDNN_TUNE_ENV(name) std::getenv(name)
+#else
+#define FDNN_TUNE_ENV(name) static_cast<const char *>(nullptr)
+#if (defined(FDNN_GEMM_DEBUG) && FDNN_GEMM_DEBUG) || (defined(FDNN_L0S_DEBUG) && FDNN_L0S_DEBUG) || (defined(FDNN_L0_DEBUG) && FDNN_L0_DEBUG) || \
+    (defined(FDNN_CHAIN_CLK) && FDNN_CHAIN_CLK) || defined(FDNN_L0S_CLK) || defined(FDNN_GEMM_PAD)
+#error "ablation / clock builds need -DFDNN_ABLATION (tools/build_variant.sh)"
+#endif
+#endif
+
 namespace fdnn {
 
 constexpr int kMaxFrameTile = 320;  // largest GEMM frame tile; scratch rows carry this much slack

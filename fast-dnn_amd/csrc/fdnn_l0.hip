@@ -1211,7 +1211,7 @@ void launch_screened_cfg(const L0Params &p, hipStream_t s) {
 }
 int l0_screen_wfr() {
   static const int wfr = [] {
-    const char *e = std::getenv("FDNN_L0_SCREEN_WFR");
+    const char *e = FDNN_TUNE_ENV("FDNN_L0_SCREEN_WFR");
     return e && std::atoi(e) == 2 ? 2 : 4;
   }();
   return wfr;
@@ -1226,7 +1226,7 @@ void launch_screened(const L0Params &p, hipStream_t s) {
 }  // namespace
 
 void launch_l0(const L0Params &p, hipStream_t s) {
-  static const bool fma_on_valu = std::getenv("FDNN_L0_FMA_VALU") != nullptr;
+  static const bool fma_on_valu = FDNN_TUNE_ENV("FDNN_L0_FMA_VALU") != nullptr;
   if (p.fma && !fma_on_valu) {
     // 32-float chunks, 4 x 2 waves (128 x 128 tile).  Measured alternatives at 10 000 frames:
     // 16-float chunks 0.221 ms, 64-float 0.205, 256-thread workgroups (two per CU) 0.205.
@@ -1235,7 +1235,7 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   }
   // Small batches (canonical flavour): the whole-K kernel, 32 x 32 tiles (100 frames: 20 -> 6 us)
   static const int small_max = [] {
-    const char *e = std::getenv("FDNN_L0_SMALL_MAX");
+    const char *e = FDNN_TUNE_ENV("FDNN_L0_SMALL_MAX");
     return e ? std::atoi(e) : 128;  // one round of 32 x 32 tiles on a 2048-node layer; beyond, the (16 | 32) x 64 tiles are as fast
   }();
   if (!p.fma && p.kernel == 0 && p.n_rows <= small_max && l0_small_geom(p.D).lds > 0) {
@@ -1250,8 +1250,8 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   //   tile64     (16 | 32 | 64) x 64 tiles, 4 outputs x 4 chains per thread and frame: 19-23 us up to 400 frames, 33-49 us up to
   //              1200, then 20 us + 35.5 ns per frame
   // e.g. 2560 frames: 120 screened, 109 chain; 3000: 110 chain, 125 the others; 6000: 174 screened, 204 chain.
-  static const bool no_screen = std::getenv("FDNN_L0_NO_SCREEN") != nullptr;
-  static const bool classic = std::getenv("FDNN_L0_CLASSIC") != nullptr;
+  static const bool no_screen = FDNN_TUNE_ENV("FDNN_L0_NO_SCREEN") != nullptr;
+  static const bool classic = FDNN_TUNE_ENV("FDNN_L0_CLASSIC") != nullptr;
   const double work = static_cast<double>(p.D) / 432.0;
   const long ft128 = (p.n_rows + 127) / 128;
   const double screened_us = 18.0 + 54.0 * work * static_cast<double>((ft128 * ((p.H + 127) / 128) + 255) / 256);
@@ -1265,9 +1265,9 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   // Round 4: the screening on the int8 matrix pipe (fdnn_l0s.hip: exact 24-bit integer images of both operands, eight
   // int8 MFMA products) + the same exact recomputation of the flagged outputs.  128 x 128 tiles, 1.85 us of matrix-pipe
   // time per tile and CU at peak: from FDNN_L0_SPLIT_MIN frames up it replaces all of the above.
-  static const bool no_split = std::getenv("FDNN_L0_NO_SPLIT") != nullptr;
+  static const bool no_split = FDNN_TUNE_ENV("FDNN_L0_NO_SPLIT") != nullptr;
   static const int split_min = [] {
-    const char *e = std::getenv("FDNN_L0_SPLIT_MIN");
+    const char *e = FDNN_TUNE_ENV("FDNN_L0_SPLIT_MIN");
     return e ? std::atoi(e) : 560;  // whole call at 512 / 600 frames: 118 / 140 us with the 64 x 64 tiles, 121 / 136 with the screening
   }();
   const bool can_split = !p.fma && !no_split && !no_screen && (p.kernel == 0 || p.kernel == 4) && !p.tap_lin && p.xd && p.xstat && p.wd && p.wstat && p.luthalf && p.glist && p.glist_count &&
@@ -1280,15 +1280,15 @@ void launch_l0(const L0Params &p, hipStream_t s) {
     // and load, five round trips instead of nine): 7.3 / 13.8 / 25.0 -- fewer flagged outputs = a latency chain, many = L2
     // gathers, where the second set of lanes only costs registers.  FDNN_L0_FIX_NB / _T / _LPO force a variant.
     static const int force_nb = [] {
-      const char *e = std::getenv("FDNN_L0_FIX_NB");
+      const char *e = FDNN_TUNE_ENV("FDNN_L0_FIX_NB");
       return e ? std::atoi(e) : 0;
     }();
     static const int force_t = [] {
-      const char *e = std::getenv("FDNN_L0_FIX_T");
+      const char *e = FDNN_TUNE_ENV("FDNN_L0_FIX_T");
       return e ? std::atoi(e) : 0;
     }();
     static const int force_lpo = [] {
-      const char *e = std::getenv("FDNN_L0_FIX_LPO");
+      const char *e = FDNN_TUNE_ENV("FDNN_L0_FIX_LPO");
       return e ? std::atoi(e) : 0;
     }();
     const int nb = force_nb ? force_nb : 3;
@@ -1327,7 +1327,7 @@ void launch_l0(const L0Params &p, hipStream_t s) {
   // 64 x 64 tile, 16-float chunks, 4 x 4 outputs per thread.  Measured alternatives: 32-float
   // chunks 0.448 ms, 8 x 4 outputs per thread 0.468 / 0.477 ms (occupancy 2) against 0.388.
   static const int t64_bk = [] {
-    const char *e = std::getenv("FDNN_L0_T64_BK");
+    const char *e = FDNN_TUNE_ENV("FDNN_L0_T64_BK");
     return e ? std::atoi(e) : 0;
   }();
   // Few frames: a 64 x 64 tile is 30-40 us of dependent vector work for ONE workgroup however few of them there are, so
@@ -1349,7 +1349,7 @@ void launch_l0(const L0Params &p, hipStream_t s) {
 // competes for.  FDNN_L0_TN=128 selects the round-1 shape.
 int l0_chain_node_tile() {
   static const int tn = [] {
-    const char *e = std::getenv("FDNN_L0_TN");
+    const char *e = std::getenv("FDNN_L0_TN") /* test hook: 128 = the round-1 tile shape, kept selectable */;
     return (e && std::atoi(e) == 128) ? 128 : 64;
   }();
   return tn;

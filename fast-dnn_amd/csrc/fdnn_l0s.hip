@@ -679,7 +679,7 @@ void launch_l0_split(const L0Params &p, hipStream_t s) {
   // equal both where both fill the chip (99.2 vs 97.7 us at 10 000 frames) and below (layer 0 at 1 000 frames 40.2 vs 40.4 us:
   // one tile's latency -- 16 chunks and a 32-output-per-lane epilogue per wave -- either way).  FDNN_L0S_WN=1|2 forces one.
   static const int wn_forced = [] {
-    const char *e = std::getenv("FDNN_L0S_WN");
+    const char *e = FDNN_TUNE_ENV("FDNN_L0S_WN");
     return e ? std::atoi(e) : 0;
   }();
   const int tiles128 = ((p.n_rows + kSTF - 1) / kSTF) * (p.h_ld / 128);

@@ -497,7 +497,10 @@ static int device_marker_state(int device) {  // 1 = this process owns the devic
   }
   return state[d];
 }
+static std::atomic<int> g_fuse_override{-1};  // fdnn_debug_set_fuse: -1 = by environment / device marker, 0 = never, 1 = always
 static bool process_may_fuse(int device) {
+  const int o = g_fuse_override.load(std::memory_order_relaxed);
+  if (o >= 0) return o == 1;
   static const int forced = [] {
     const char *e = std::getenv("FDNN_FUSE_NORM");
     return e ? (std::atoi(e) != 0 ? 1 : 0) : -1;
@@ -576,7 +579,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
     g.fuse_flag = c->d_fuse_flag;
     g.fuse_giveups = m->d_l0_stats ? m->d_l0_stats + 2 : nullptr;
     static const int stagger = [] {
-      const char *e = std::getenv("FDNN_FUSE_STAGGER");
+      const char *e = FDNN_TUNE_ENV("FDNN_FUSE_STAGGER");
       return e ? std::atoi(e) : 0;
     }();
     g.fuse_stagger = stagger;
@@ -593,7 +596,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
       FuseChain &fc = fuse_chain(m->device);
       std::lock_guard<std::mutex> lk(fc.mu);
       if (!fc.ev) HIP_TRY(hipEventCreateWithFlags(&fc.ev, hipEventDisableTiming | hipEventDisableSystemFence));
-      static const bool eager = std::getenv("FDNN_EAGER_EVENTS") != nullptr;
+      static const bool eager = FDNN_TUNE_ENV("FDNN_EAGER_EVENTS") != nullptr;
       if (fc.last_stream != s || !(fc.pending || fc.recorded)) {  // (same stream as the previous fused launch: in order already)
         if (fc.pending) {  // the deferred record: the tail of the previous launch's stream is behind that launch
           fc.pending = false;
@@ -652,7 +655,7 @@ bool output_will_fuse(fdnn_ctx *c, int count, const int8_t *d_masks) {
 // hand-made pipeline over pinned bounce buffers with parallel host memcpy: 7.9 / 23.5 ms.)
 // Synchronises the stream.
 int copy_out(void *dst, const void *d_src, size_t bytes, hipStream_t s) {
-  static const bool plain = std::getenv("FDNN_PLAIN_COPY_OUT") != nullptr;
+  static const bool plain = FDNN_TUNE_ENV("FDNN_PLAIN_COPY_OUT") != nullptr;
   if (bytes >= (size_t(64) << 20) && !plain) {
     const unsigned hw = std::thread::hardware_concurrency();
     const int T = static_cast<int>(std::min<unsigned>(16, std::max<unsigned>(1, hw / 2)));
@@ -754,7 +757,7 @@ hipError_t ctx_enter(fdnn_ctx *c, hipStream_t s) {
   return hipStreamWaitEvent(s, c->done, 0);
 }
 void ctx_leave(fdnn_ctx *c, hipStream_t s) {
-  static const bool eager = std::getenv("FDNN_EAGER_EVENTS") != nullptr;  // (measurements: every record made at once, as before round 4)
+  static const bool eager = FDNN_TUNE_ENV("FDNN_EAGER_EVENTS") != nullptr;  // (measurements: every record made at once, as before round 4)
   c->done_stream = s;
   if (stream_is_durable(c, s) && !eager) {
     c->done_pending = true;
@@ -984,6 +987,12 @@ int fdnn_device_shared(int device) {
   return device_marker_state(device) == 1 ? 0 : 1;
 }
 
+int fdnn_debug_set_fuse(int mode) {
+  if (mode < -1 || mode > 1) return fail(FDNN_E_ARG, "fuse mode must be -1, 0 or 1");
+  g_fuse_override.store(mode, std::memory_order_relaxed);
+  return FDNN_OK;
+}
+
 int fdnn_debug_set_l0_list_cap(fdnn_model *m, int cap) {
   if (!m || cap < 0) return fail(FDNN_E_ARG, "bad argument");
   std::lock_guard<std::mutex> lk(m->mu);
@@ -1156,7 +1165,7 @@ int fdnn_ctx_lazy_output_batch_bits_device(fdnn_ctx *c, int first, int count, co
 // is used.  Synchronises the stream.
 static int lazy_copy_out(fdnn_ctx *c, int count, const uint64_t *d_bits, const uint64_t *bits, float *out, hipStream_t s) {
   const size_t O = size_t(c->m->hm.hdr.out_dim), wpr = (O + 63) / 64;
-  static const bool no_compact = std::getenv("FDNN_LAZY_NO_COMPACT") != nullptr;
+  static const bool no_compact = FDNN_TUNE_ENV("FDNN_LAZY_NO_COMPACT") != nullptr;
   size_t most = 0;
   const uint64_t tail_mask = (O & 63) ? ((uint64_t(1) << (O & 63)) - 1) : ~uint64_t(0);
   for (int f = 0; f < count; ++f) {

@@ -147,7 +147,7 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
   // the next batch's layer 0, which must then be the all-VALU chain kernel (the matrix-pipe kernels fill the register
   // file) -- worth it while layer 0 took 270 us; with the int8 screening (140 us) the chain kernel's 325 us lose.
   static const bool overlap = [] {
-    const char *e = std::getenv("FDNN_SERVER_OVERLAP");
+    const char *e = FDNN_TUNE_ENV("FDNN_SERVER_OVERLAP");
     return e ? std::atoi(e) != 0 : false;
   }();
   const std::vector<std::pair<int, int>> chunks = small ? std::vector<std::pair<int, int>>{} : fdnn::frame_chunks(n);

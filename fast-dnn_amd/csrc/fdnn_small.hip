@@ -436,7 +436,7 @@ bool qgemm_small_ok(int K, int fastdiv) { return fastdiv && K <= kSmWaves * kSmS
 // FDNN_SMALL_NTM=1|2 forces one shape (measurements).
 void launch_qgemm_small_hidden(const QGemmParams &p, hipStream_t s) {
   static const int forced = [] {
-    const char *e = std::getenv("FDNN_SMALL_NTM");
+    const char *e = FDNN_TUNE_ENV("FDNN_SMALL_NTM");
     return e ? std::atoi(e) : 0;
   }();
   const long wg32 = static_cast<long>(p.rows_pad / 32) * (p.n_pad / kSmFT);

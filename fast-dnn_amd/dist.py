@@ -26,7 +26,7 @@ def frame_shards(n_frames: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def broadcast_blob(blob, rank: int, world: int, device, src: int = 0):
+def broadcast_blob(blob, rank: int, world: int, device, src: int = 0, force: bool = False):
     """Broadcast a uint8 tensor whose length only ``src`` knows.  ``blob`` is the
     payload tensor on ``src`` (any value elsewhere); returns the payload on every
     rank.  Works on whatever backend the default process group uses (nccl = RCCL
@@ -34,7 +34,7 @@ def broadcast_blob(blob, rank: int, world: int, device, src: int = 0):
     import torch
     import torch.distributed as dist
 
-    if world == 1:
+    if world == 1 and not force:  # (force: run the collectives on a one-rank group -- proves the backend loads and moves device tensors)
         return blob
     size = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == src:
@@ -46,7 +46,7 @@ def broadcast_blob(blob, rank: int, world: int, device, src: int = 0):
     return blob
 
 
-def load_replicated(model_path: str, device_index: int, rank: int, world: int, host_broadcast: bool = False):
+def load_replicated(model_path: str, device_index: int, rank: int, world: int, host_broadcast: bool = False, force_collective: bool = False):
     """QuantizedDnn.loadFromFile on rank 0 + RCCL broadcast of the packed weights.
 
     ``host_broadcast``: the default process group is gloo (several ranks sharing one device, where
@@ -56,7 +56,7 @@ def load_replicated(model_path: str, device_index: int, rank: int, world: int, h
     from . import api
 
     dev = torch.device("cuda", device_index)
-    if world == 1:
+    if world == 1 and not force_collective:
         return api.QuantizedDnn.loadFromFile(model_path, device=device_index)
     blob = None
     dnn = None
@@ -69,9 +69,12 @@ def load_replicated(model_path: str, device_index: int, rank: int, world: int, h
     if host_broadcast:
         blob = broadcast_blob(blob.cpu() if rank == 0 else None, rank, world, torch.device("cpu")).to(dev)
     else:
-        blob = broadcast_blob(blob, rank, world, dev)
-    if rank != 0:
+        blob = broadcast_blob(blob, rank, world, dev, force=force_collective)
+    if rank != 0 or force_collective:
+        # (force_collective on one rank: the model that scores is the one IMPORTED from the broadcast buffer, as on ranks > 0)
         torch.cuda.synchronize()
+        if dnn is not None:
+            dnn.delete()
         dnn = api.QuantizedDnn.fromDeviceBlob(blob.data_ptr(), blob.numel(), device_index)
     return dnn
 

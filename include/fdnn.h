@@ -270,6 +270,11 @@ FDNN_API int fdnn_debug_frame_chunks(int n, int *chunks, int cap);
  * available (batches of 2048 frames and more, no taps). */
 FDNN_API int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind);
 
+/* Tests only, process-wide: 0 = large batches scale their soft-max in a separate pass (what FDNN_FUSE_NORM=0 or a second
+ * process on the GPU selects), 1 = inside the output kernel wherever the shape allows, -1 = the default rule.  Results are
+ * bit-identical (one tree order for the row total everywhere).  SoftMax::apply, dnn.cc:534-544. */
+FDNN_API int fdnn_debug_set_fuse(int mode);
+
 /* Tests only: cap the per-launch list of flagged layer-0 outputs (int8 screening) of contexts created AFTER the call at
  * `cap` entries (0 = the default, 1/16 of the outputs), so that a small batch overflows it: tiles that no longer fit take
  * the whole-tile recomputation, results unchanged.  Drops the model's pooled contexts.  InputActivations, dnn.cc:219-247. */

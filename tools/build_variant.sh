@@ -7,7 +7,7 @@ set -e
 NAME=$1; EXTRA=$2
 cd "$(dirname "$0")/../fast-dnn_amd/csrc"
 OUT=../lib; V=$OUT/variant_$NAME; mkdir -p $V
-FLAGS="-O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wno-unused-result -Wno-unused-value -Wno-pass-failed $EXTRA"
+FLAGS="-DFDNN_ABLATION -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wno-unused-result -Wno-unused-value -Wno-pass-failed $EXTRA"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS -c fdnn_gemm.hip -o $V/fdnn_gemm.o &
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS -fno-slp-vectorize -c fdnn_l0.hip -o $V/fdnn_l0.o &
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS -c fdnn_kernels.hip -o $V/fdnn_kernels.o &
