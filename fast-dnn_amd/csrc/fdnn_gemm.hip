@@ -500,7 +500,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     }
   }
   if constexpr (FUSED) {
-    static_assert(!FUSED || (OUTPUT && PLAIN && FAST && !ANYW && !TAP && WM == 4), "fused soft-max: the dense / batched-lazy production instances only");
+    static_assert(!FUSED || (OUTPUT && PLAIN && FAST && !TAP && WM == 4), "fused soft-max: the dense / batched-lazy production instances only");
+    // (ANYW, round 5: output widths that are not a multiple of 32 -- pdf counts are arbitrary, dnn.cc:428-454 takes any width --
+    // per-element range test in phase 1, plain 4-byte-aligned stores and a scalar tail in phase 2)
     // ---------------------------------------------------------------- fused soft-max
     // SoftMax::apply (dnn.cc:534-544) inside the output kernel.  Phase 1: e = exp(z) replaces each accumulator IN
     // PLACE (160 registers per lane stay live), the 64-node partial sums P are formed exactly as in the unfused
@@ -569,7 +571,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
               if (((nib >> (2 * h2 + 1)) & 1u) == 0) z.y = 0.0f;
             }
             const v2f_e y = z * log2e2;
-            const v2f_e ex = v2f_e{__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)} * v2f_e{in4 ? 1.0f : 0.0f, in4 ? 1.0f : 0.0f};
+            const v2f_e keep = ANYW ? v2f_e{nb + 2 * h2 < p.rows ? 1.0f : 0.0f, nb + 2 * h2 + 1 < p.rows ? 1.0f : 0.0f} : v2f_e{in4 ? 1.0f : 0.0f, in4 ? 1.0f : 0.0f};
+            const v2f_e ex = v2f_e{__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)} * keep;
             e[2 * h2] = ex.x;
             e[2 * h2 + 1] = ex.y;
           }
@@ -692,7 +695,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
 #if FDNN_GEMM_DEBUG & 128  // (timing build: the probabilities do not leave)
         if (ff < 0 && ncol0 + col + 4 <= p.rows) store_wt(p.final + static_cast<size_t>(ff) * p.rows + ncol0 + col, v);
 #else
-        if (ff < p.n && ncol0 + col + 4 <= p.rows) store_wt(p.final + static_cast<size_t>(ff) * p.rows + ncol0 + col, v);
+        if (!ANYW) {
+          if (ff < p.n && ncol0 + col + 4 <= p.rows) store_wt(p.final + static_cast<size_t>(ff) * p.rows + ncol0 + col, v);
+        } else if (ff < p.n) {
+          // rows of any width: a group of four starts on a 4-byte boundary only, and rows share cache lines -- plain stores
+          // (written through, a line shared by two rows becomes partial-line writes to memory), scalar ones for a row's last group
+          float *op = p.final + static_cast<size_t>(ff) * p.rows + ncol0 + col;
+          if (ncol0 + col + 4 <= p.rows) {
+            typedef float v4f_a4 __attribute__((ext_vector_type(4), aligned(4)));
+            *reinterpret_cast<v4f_a4 *>(op) = v4f_a4{v.x, v.y, v.z, v.w};
+          } else {
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            for (int q = 0; q < 4; ++q)
+              if (ncol0 + col + q < p.rows) op[q] = vv[q];
+          }
+        }
 #endif
 #endif
       }
@@ -734,10 +751,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     }
     if (tid == 0) {
       if (gave_up) {
-        __hip_atomic_store(p.fuse_flag + static_cast<size_t>(nt) * MT + mt, gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (ANYW stores are plain: written back to memory by the release BEFORE the flag can be seen; the write-through
+        // stores of the other instances are there already -- every wave drained them above)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p.fuse_flag + static_cast<size_t>(nt) * MT + mt, gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      const uint32_t prev = __hip_atomic_fetch_add(cnt + 7, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // acq_rel (advisor, round 4): the last workgroup's reads of the flags and of the unscaled blocks below are ordered behind
+      // every leaver's add, by the memory model and not only by their cache policy
+      const uint32_t prev = __hip_atomic_fetch_add(cnt + 7, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
       ok_s[2] = prev == static_cast<uint32_t>(MT) - 1u ? 1 : 0;
     }
     __syncthreads();
@@ -758,12 +780,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
             // tile j's 256 columns of the part's frames: 64 four-column pieces per frame
             for (int it = tid; it < FT * 64; it += Cfg::THREADS) {
               const int f = it >> 6, c4 = j * 256 + 4 * (it & 63), frame = nt * FT + f;
-              if (part_of_row(f) != part || frame >= p.n || c4 + 4 > p.rows) continue;  // (rows % 32 == 0 on this path)
+              if (part_of_row(f) != part || frame >= p.n || c4 >= p.rows) continue;
               float *at = p.final + static_cast<size_t>(frame) * p.rows + c4;
-              v4f_t v;
-              asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(at) : "memory");
               const float iv = inv_s[f];
-              store_wt(at, v4f_t{v.x * iv, v.y * iv, v.z * iv, v.w * iv});
+              if (c4 + 4 <= p.rows) {
+                v4f_t v;
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(at) : "memory");
+                store_wt(at, v4f_t{v.x * iv, v.y * iv, v.z * iv, v.w * iv});
+              } else {  // (ANYW) a row's last, partial group
+                for (int q = 0; c4 + q < p.rows; ++q) {
+                  const float v = __hip_atomic_load(at + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(at + q, v * iv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+              }
             }
           }
         }
@@ -1071,6 +1100,8 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
   constexpr bool kCanFuse = OUTPUT && FAST && WM == 4 && NF >= 4;  // the 8-wave shapes and the 4-wave 128- / 160-frame shapes (two workgroups per CU)
   auto k_fused = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, false, false, WM, kCanFuse>;  // (= k_plain where it cannot)
   auto k_fused_masked = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, kCanFuse, false, WM, kCanFuse>;
+  auto k_fused_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, false, kCanFuse, WM, kCanFuse>;  // widths % 32 != 0
+  auto k_fused_masked_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, kCanFuse, kCanFuse, WM, kCanFuse>;
   // the attribute is per device: a process may hold models on several GPUs
   static std::atomic<unsigned long long> attr_set{0};
   int dev = 0;
@@ -1085,12 +1116,17 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_masked_anyw), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_masked), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_anyw), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_masked_anyw), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
   if (kCanFuse && p.fuse_s != nullptr) {
     // fused soft-max: the node tiles of a frame tile are consecutive blocks (what a workgroup that gave up waiting left
     // unscaled is scaled by its frame tile's last workgroup: one launch)
-    hipLaunchKernelGGL(p.mask ? k_fused_masked : k_fused, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+    if ((p.rows & 31) != 0)
+      hipLaunchKernelGGL(p.mask ? k_fused_masked_anyw : k_fused_anyw, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+    else
+      hipLaunchKernelGGL(p.mask ? k_fused_masked : k_fused, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   } else if (p.tap_acc)
     hipLaunchKernelGGL(k_tap, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else if (OUTPUT && p.mask == nullptr && (p.rows & 31) == 0)
@@ -1244,7 +1280,7 @@ bool qgemm_fused_ok(const QGemmParams &p) {
     const char *e = std::getenv("FDNN_FUSE_NORM");
     return e && std::atoi(e) == 0;
   }();
-  if (off || p.small || p.node_tile != 256 || !p.fastdiv || (p.mask && !p.mask_bits) || p.tap_acc || p.tap_logit || (p.rows & 31) != 0) return false;
+  if (off || p.small || p.node_tile != 256 || !p.fastdiv || (p.mask && !p.mask_bits) || p.tap_acc || p.tap_logit) return false;
   if (p.frame_tile != 320 && p.frame_tile != 256 && p.frame_tile != 160 && p.frame_tile != 128) return false;
   const int MT = p.rows_pad / 256;
   int L = 1;

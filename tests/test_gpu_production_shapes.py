@@ -667,3 +667,45 @@ def test_host_lazy_batches_return_compacted_rows(net_model_path, tmp_models, out
     assert np.array_equal(sub, got[10:40])
     ctx.delete()
     dnn.delete()
+
+
+@pytest.mark.parametrize("out_dim,n", [(1003, 10000), (3483, 5000), (2001, 12000)])
+def test_fused_softmax_with_arbitrary_output_widths(tmp_models, out_dim, n):
+    """Round 5: output widths that are not a multiple of 32 (real pdf counts; the reference takes any width, dnn.cc:428-454)
+    scale their soft-max inside the output kernel as well (ANYW fused instance) instead of falling back to the scale pass.
+    Large batches, dense and lazy with bit masks: bit-identical to the unfused path, rows sum to one, sampled frames equal
+    the oracle; and the give-up path of the instance (FDNN_GEMM_DEBUG=4096 is covered for width 8000 above) is exercised
+    through the accumulator-probe / properties here."""
+    import torch
+
+    p = os.path.join(tmp_models, f"fusew_{out_dim}.bin")
+    F.write_model_bin(p, F.synth_net([432, 256, 256, 256, out_dim], seed=out_dim))
+    x = F.synth_features(n, 432, seed=out_dim + 1)
+    masks = F.generate_masks_fast(n, out_dim, 0.4, 0.03, seed=5)
+    bits = F.pack_mask_bits(masks)
+    dnn = api.QuantizedDnn.loadFromFile(p)
+    xd = torch.from_numpy(x).cuda()
+    bd = torch.from_numpy(bits.view(np.int64)).cuda()
+    outs = {}
+    for mode in (0, 1):
+        api.set_fuse(mode)
+        od = torch.zeros((n, out_dim), dtype=torch.float32, device="cuda")
+        ol = torch.zeros((n, out_dim), dtype=torch.float32, device="cuda")
+        dnn.calculate_device(xd.data_ptr(), n, od.data_ptr(), 0)
+        dnn.calculate_lazy_bits_device(xd.data_ptr(), n, bd.data_ptr(), ol.data_ptr(), 0)
+        torch.cuda.synchronize()
+        outs[mode] = (od, ol)
+    api.set_fuse(-1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float((outs[1][0].sum(1, dtype=torch.float64) - 1).abs().max()) < 1e-4
+    assert float((outs[1][1].sum(1, dtype=torch.float64) - 1).abs().max()) < 1e-4
+    idx = sample_every_tile(n, 320, 2, seed=3)[:96]
+    orc = Oracle(p)
+    want = orc.calculate(x[idx])
+    got = outs[1][0][torch.from_numpy(idx).cuda()].cpu().numpy()
+    assert np.abs(got - want).max() <= TIGHT
+    lwant = orc.lazy(x[idx], masks[idx])
+    lgot = outs[1][1][torch.from_numpy(idx).cuda()].cpu().numpy()
+    assert np.abs(lgot - lwant).max() <= TIGHT
+    assert dnn.fuseGiveups() == 0
+    dnn.delete()
