@@ -42,6 +42,9 @@
 #ifndef FDNN_CHAIN_A_AUX
 #define FDNN_CHAIN_A_AUX 17  // cache policy of the activation rows' LDS-DMA loads: sc0 | sc1 (they were written by other workgroups of this launch)
 #endif
+#ifndef FDNN_CHAIN_GROUP
+#define FDNN_CHAIN_GROUP 1  // frame tiles of a queue that wait for one another as a group between layers (1: each on its own)
+#endif
 #ifndef FDNN_CHAIN_EARLY_W
 #define FDNN_CHAIN_EARLY_W 1  // the next task's weight stages are requested before the wait for its activation rows
 #endif
@@ -101,14 +104,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qchain_kernel(QChainParams p)
   // (thread 0 keeps its home queue and whether that queue still has tasks in LDS: ctl_s[1], ctl_s[2] (0 = yes, 8 = exhausted))
   struct Dec {
     int l, nt, mt;
+    int gnt, gtarget;  // the sync group's leading frame tile (its counters are the group's) and its tasks per layer
   };
   auto decode = [&](KP k, int task) -> Dec {
     const int MT = k->rows_pad / G_BM, NT = k->n_pad / FT;
     const int q = task >> 24, ti = task & 0xffffff;
-    const int per_layer = ((NT - q + 7) >> 3) * MT;
+    const int nft = (NT - q + 7) >> 3;
+    const int per_layer = nft * MT;
     const int l = ti / per_layer, r = ti - l * per_layer;
     const int ftl = r / MT;
-    return Dec{l, q + 8 * ftl, r - ftl * MT};
+    const int g0 = ftl / FDNN_CHAIN_GROUP * FDNN_CHAIN_GROUP;
+    const int gsz = min(FDNN_CHAIN_GROUP, nft - g0);
+    return Dec{l, q + 8 * ftl, r - ftl * MT, q + 8 * g0, gsz * MT};
   };
   auto queue_tasks = [&](KP k, int q) { return ((k->n_pad / FT - q + 7) >> 3) * (k->rows_pad / G_BM) * k->n_layers; };  // frame tiles q, q + 8, ... < NT
   // thread 0: a task from the queue with the most tasks left (its own while that has any), or -1.  All eight heads are read
@@ -252,8 +259,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qchain_kernel(QChainParams p)
       const Dec d = decode(kp, task);
       if (d.l > 0) {
         if (tid == 0) {
-          const uint32_t *dn = kp->done + static_cast<size_t>(d.nt) * kp->n_layers + (d.l - 1);
-          const uint32_t want = static_cast<uint32_t>(kp->rows_pad / G_BM);
+          const uint32_t *dn = kp->done + static_cast<size_t>(d.gnt) * kp->n_layers + (d.l - 1);
+          const uint32_t want = static_cast<uint32_t>(d.gtarget);
           int spins = 0;
           while (__hip_atomic_load(dn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(FDNN_CHAIN_SLEEP);
@@ -298,6 +305,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qchain_kernel(QChainParams p)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage 0 (and the table, the biases, stage 1's weights) landed
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      CH_TS(7);  // (stage 0 has landed)
       load_frags(smem, smem + Cfg::W_BYTES, 0, 0);
       if (KT > 1) {
 #pragma unroll
@@ -490,11 +498,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qchain_kernel(QChainParams p)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // my rows have been acknowledged (write-through: they are in memory)
     CH_TS(5);
     // ================================================================ phase D: next task, arrival
-    int done_l = 0, done_nt = 0;
+    int done_l = 0, done_nt = 0, done_target = 0;
     {
       const Dec d = decode(kp, task);
       done_l = d.l;
-      done_nt = d.nt;
+      done_nt = d.gnt;
+      done_target = d.gtarget;
     }
     if (tid == 0) {
       int t;
@@ -512,7 +521,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qchain_kernel(QChainParams p)
       const int NL = kp->n_layers;
       uint32_t *dn = kp->done + static_cast<size_t>(done_nt) * NL;
       const uint32_t prev = __hip_atomic_fetch_add(dn + done_l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (done_l == NL - 1 && prev == static_cast<uint32_t>(kp->rows_pad / G_BM) - 1u) {  // the frame tile's last task: its counters are ready for the next launch
+      if (done_l == NL - 1 && prev == static_cast<uint32_t>(done_target) - 1u) {  // the frame tile's last task: its counters are ready for the next launch
         for (int i = 0; i < NL; ++i) __hip_atomic_store(dn + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
@@ -525,7 +534,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qchain_kernel(QChainParams p)
         long long *o = clk + 8 + static_cast<size_t>(slot) * 10;
         o[0] = (static_cast<long long>(blockIdx.x) << 32) | static_cast<uint32_t>(task);
         o[1] = (static_cast<long long>(xcc_id()) << 32) | static_cast<uint32_t>((done_l << 16) | done_nt);
-        o[2] = static_cast<long long>(__builtin_amdgcn_s_memrealtime());
+        o[2] = tc[7];  // stage 0 landed
         for (int i = 0; i < 7; ++i) o[3 + i] = tc[i];
       }
     }

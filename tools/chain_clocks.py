@@ -39,5 +39,5 @@ for b in np.unique(blk):
     per_blk[b] = (int(tc[m, 0].min() - t0), int(tc[m, 6].max() - t0), int(m.sum()))
 v = np.array(list(per_blk.values()))
 print("workgroups", len(per_blk), "first start spread", int(v[:, 0].max()), "last end min/max", int(v[:, 1].min()), int(v[:, 1].max()), "tasks per wg min/max", int(v[:, 2].min()), int(v[:, 2].max()))
-wall = r[:, 2]
-print("wall clock span of the launch (100 MHz ticks):", int(wall.max() - wall.min()))
+land = r[:, 2] - tc[:, 2]
+print("stage 0 landed after the wait: mean cycles", int(land.mean()), "by layer", [int(land[lay == l].mean()) for l in range(int(lay.max()) + 1)])
