@@ -720,7 +720,7 @@ def main() -> None:
         # WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes); bench.py
         # itself cannot run under rocprof.  Newest round first.
         pmc, pmc_file = {}, None
-        for cand in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for cand in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 pmc_file = cand
@@ -785,7 +785,7 @@ def main() -> None:
         gemm = next(k for k in kinds if k["kernel"].startswith("qgemm_kernel<hidden>"))
         rocprof = None
         try:  # the same fractions from the committed rocprofv3 averages (tools/profile_round.sh)
-            rocprof = json.load(open(os.path.join(ROOT, "profiles", "r04_roofline.json")))
+            rocprof = json.load(open(os.path.join(ROOT, "profiles", "r05_roofline.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_roofline.json")) else "r04_roofline.json")))
         except Exception:
             pass
         value = world * n * steps / elapsed
@@ -818,7 +818,7 @@ def main() -> None:
             "single_stream": {"frames_per_s": round(world * n * steps / single_elapsed, 1), "ms_per_step": round(single_elapsed / steps * 1e3, 4),
                               "note": "the same K steps as back-to-back fdnn_calculate_device calls on one stream (no overlap between steps)"},
             "roofline": dict(dominant, note="largest share of the step; times from HIP events on the launch stream, which add ~4 us per "
-                                            "bracketed launch -- profiles/r04_roofline.json holds the rocprofv3 averages"),
+                                            "bracketed launch -- profiles/r05_roofline.json holds the rocprofv3 averages"),
             "roofline_int8_gemm": gemm,
             "roofline_kernels": kinds,
             "end_to_end": {"bound": "mfma", "achieved": round(value / world, 1), "peak": round(ROOFLINE_FRAMES_PER_S, 1), "unit": "frames/s per GPU",

@@ -591,23 +591,20 @@ bool qchain_ok(int rows_pad, int K, int n, int n_layers) {
   }();
   static const int env_min = [] {
     const char *e = std::getenv("FDNN_CHAIN_MIN");
-    return e ? std::atoi(e) : 4097;
+    return e ? std::atoi(e) : 9800;
   }();
   const int forced = g_chain_mode.load(std::memory_order_relaxed), forced_min = g_chain_min.load(std::memory_order_relaxed);
-  const int mode = forced >= 0 ? forced : env_mode;  // -1: by the cost rule below, 0: never, 1: whenever the shape allows
+  // From ~9 800 frames up -- a round of 256-node x 320-frame tiles and more -- the chain is the faster form at EVERY size
+  // (tools/chain_sweep.py, layer 0 + six hidden layers, chained / per-layer: 10 000 frames 0.98, 10 241 0.88, 12 000 0.86,
+  // 15 360 0.93, 20 480 0.97): its tasks flow across the layers where a launch per layer idles most of the chip in every
+  // partial round.  Below, the per-layer path has better tiles for the size (160- / 128-frame four-wave shapes, two workgroups
+  // per CU) and the chain's 320-frame tasks leave CUs without work: 9 000 frames 1.04, 8 000 1.21, 6 000 1.33, 4 097 1.33.
+  const int mode = forced >= 0 ? forced : env_mode;  // 0: never; otherwise from min_frames up
   const int min_frames = (forced >= 0 && forced_min > 0) ? forced_min : env_min;
   if (mode == 0 || n_layers < 2 || n_layers > kMaxChainLayers || K % 128 != 0 || n < min_frames) return false;
-  if (mode == 1) return true;
-  // One launch per layer costs ceil(tiles / CUs) rounds per layer -- a partly filled last round idles the other CUs, once
-  // per layer; the chain's tasks flow across the layers, ceil(layers x tiles / CUs) task times in all.  Where the two
-  // counts are equal (10 240 frames on a 2048-wide net: one full round per layer) the two forms measure the same
-  // (bench step 0.6067 vs 0.6068 ms) and the per-layer kernels stay; the chain runs where it saves task times:
-  // 12 000 frames 427 -> 338 us for six layers, 20 000 frames 548 -> 532.
-  const int ft = qchain_frame_tile(rows_pad, n);
-  const long tiles = static_cast<long>(rows_pad / 256) * ((n + ft - 1) / ft);
-  const long cus = 256;
-  const long per_layer = n_layers * ((tiles + cus - 1) / cus), chained = (n_layers * tiles + cus - 1) / cus;
-  return chained < per_layer;
+  (void)rows_pad;
+  (void)mode;
+  return true;
 }
 
 int qchain_frame_tile(int rows_pad, int n) {

@@ -151,16 +151,13 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
 bool output_will_fuse(fdnn_ctx *c, int count, const int8_t *d_masks);
 // A pass over a very large batch runs as chunks (frames are independent: a chunk is a batch of its own, and the scratch
 // context only has to hold one).  kRoundFrames = 32 frame tiles of 320 = one workgroup per CU in the 2048-wide hidden
-// layers, the unit the layer times grow in; a chunk is two rounds.  Measured, 125 000 frames (the 8-GPU shard of
-// BASELINE configs[4]), fused soft-max: 12.09 M frames/s as one batch (4 GB of result rows, 512 MB of activations per
-// layer: the address-translation and Infinity caches stop covering the working set), 12.87 M in chunks of one round,
-// 13.14 M in chunks of two (tools/chunk_bench.py; round 2, unfused: 10.1 M whole, 11.4 M chunked).  Returns (offset,
-// count) pairs, the largest first.  The frames past the last whole round stay with it unless they are few
-// (<= kChunkTailSplit), in which case they are cheaper as a small batch of their own than as one more, nearly empty
-// round of workgroups in every layer.
+// layers; a chunk is two rounds.  Measured, 125 000 frames (the 8-GPU shard of BASELINE configs[4]), fused soft-max:
+// 12.09 M frames/s as one batch (4 GB of result rows, 512 MB of activations per layer: the address-translation and Infinity
+// caches stop covering the working set), 12.87 M in chunks of one round, 13.14 M in chunks of two (tools/chunk_bench.py).
+// Returns (offset, count) pairs: chunks of kChunkFrames, then what is left as one more batch.  (Up to round 4 a small tail
+// past a whole round was split off as a batch of its own; the chained hidden layers made that unnecessary: frame_chunks.)
 constexpr int kRoundFrames = 10240;
 constexpr int kChunkFrames = 2 * kRoundFrames;
-constexpr int kChunkTailSplit = 2048;
 std::vector<std::pair<int, int>> frame_chunks(int n);
 // Ordering between the streams a context is used on.  An event record costs 3-4 us of queue time behind the kernel it
 // follows, so a context whose work went to a stream that is certain to exist later -- its own, its owner's, or the null

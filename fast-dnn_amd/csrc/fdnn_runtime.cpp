@@ -718,28 +718,21 @@ std::vector<std::pair<int, int>> frame_chunks(int n) {
     const int v = e ? std::atoi(e) : kChunkFrames;
     return v <= 0 ? 0 : std::max(kRoundFrames, v / kRoundFrames * kRoundFrames);
   }();
-  if (kChunk <= 0 || n <= kRoundFrames) {
+  if (kChunk <= 0 || n <= kChunk) {
     out.emplace_back(0, n);
     return out;
   }
-  // Whole rounds go in chunks of kChunk frames.  What is left over is less than a chunk: a SMALL tail -- a few more
-  // frame tiles than the CUs hold, i.e. one more, nearly empty round of workgroups in every layer (11 000 frames as one
-  // batch: 977 us) -- goes as a small batch of its own (754 + 150 us); from ~2 000 frames on the extra round is worth
-  // its time and the tail stays with the last whole round (14 000 frames: 1 100 us either way).  tools/batch_sweep.py,
-  // tools/chunk_bench.py.
-  const int tail = n % kRoundFrames;
-  const bool own_tail = tail > 0 && tail <= kChunkTailSplit;
-  int off = 0, body = n - tail;  // whole rounds
-  while (body - off >= kChunk) {
+  // Chunks of kChunk frames, what is left over as one more batch.  (Rounds 2-4 kept a batch to whole rounds of workgroups and
+  // split a small tail off as a batch of its own -- 11 000 frames as one batch cost a second, nearly empty round in every
+  // hidden layer: 977 us against 754 + 150.  From ~9 800 frames up the hidden layers now run as one chained launch whose
+  // tasks flow across the layers (fdnn_chain.hip), the partial round is gone -- 11 000 frames: layer 0 + hidden layers 534 ->
+  // 459 us -- and a tail costs less inside the batch than as a call of its own: tools/chain_sweep.py, tools/batch_sweep.py.)
+  int off = 0;
+  while (n - off > kChunk) {
     out.emplace_back(off, kChunk);
     off += kChunk;
   }
-  if (own_tail || tail == 0) {
-    if (body > off) out.emplace_back(off, body - off);
-    if (tail) out.emplace_back(body, tail);
-  } else {
-    out.emplace_back(off, n - off);  // the last whole rounds (if any) and the tail: less than a chunk
-  }
+  out.emplace_back(off, n - off);
   return out;
 }
 

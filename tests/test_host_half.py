@@ -107,21 +107,21 @@ def test_error_paths(tmp_path, tiny_model_path):
 
 def test_very_large_batches_are_cut_into_whole_rounds():
     """Chunking of very large passes (the device-side counterpart of the reference's frame blocks, dnn.cc:402-454:
-    blocking never changes a result): the chunks tile [0, n) in order, none exceeds 20 480 frames, the largest comes
-    first (the scoring loop sizes its decisions by it), every chunk but the last two is whole 10 240-frame rounds, and
-    a few frames past a whole round become a small batch of their own instead of a second round of workgroups."""
+    blocking never changes a result): the chunks tile [0, n) in order, none exceeds 20 480 frames, every chunk but the last
+    is 20 480 frames, and up to 20 480 frames a pass is one batch (round 5: the chained hidden layers took the partial
+    rounds of workgroups away, so a tail is no longer split off)."""
     for n in list(range(1, 200, 7)) + [10239, 10240, 10241, 11000, 12288, 12289, 15000, 20480, 20481, 22528, 22529, 25000, 31000,
                                         33000, 125000, 1000000, 20971520]:
         ch = api.frame_chunks(n)
         assert ch[0][0] == 0 and sum(c for _, c in ch) == n
         assert all(a[0] + a[1] == b[0] for a, b in zip(ch, ch[1:]))
         assert all(0 < c <= 20480 for _, c in ch) and ch[0][1] == max(c for _, c in ch)
-        assert all(c % 10240 == 0 for _, c in ch[:-2])
+        assert all(c == 20480 for _, c in ch[:-1])
     assert api.frame_chunks(10240) == [(0, 10240)]
-    assert api.frame_chunks(11000) == [(0, 10240), (10240, 760)]
+    assert api.frame_chunks(11000) == [(0, 11000)]
     assert api.frame_chunks(15000) == [(0, 15000)]
     assert api.frame_chunks(33000) == [(0, 20480), (20480, 12520)]
-    assert api.frame_chunks(31000) == [(0, 20480), (20480, 10240), (30720, 280)]
+    assert api.frame_chunks(31000) == [(0, 20480), (20480, 10520)]
 
 
 def test_no_cpu_fallback_without_a_gpu(tiny_model_path):
