@@ -602,13 +602,21 @@ bool qchain_ok(int rows_pad, int K, int n, int n_layers) {
   const int mode = forced >= 0 ? forced : env_mode;  // 0: never; otherwise from min_frames up
   const int min_frames = (forced >= 0 && forced_min > 0) ? forced_min : env_min;
   if (mode == 0 || n_layers < 2 || n_layers > kMaxChainLayers || K % 128 != 0 || n < min_frames) return false;
-  (void)rows_pad;
-  (void)mode;
-  return true;
+  if (forced == 1) return true;  // (tests / measurements: wherever the shape allows)
+  // ... and only where a launch per layer would run a partly filled round: at whole rounds of 320-frame tiles (10 000 /
+  // 10 240 / 20 480 frames on a 2048-wide net) the two forms are within +-2 % of each other, the sign depending on the box.
+  const long tiles = static_cast<long>(rows_pad / 256) * ((n + 319) / 320), cus = 256;
+  const long idle = (tiles + cus - 1) / cus * cus - tiles;
+  return idle >= 24;
 }
 
 int qchain_frame_tile(int rows_pad, int n) {
   (void)rows_pad;
+  static const int forced = [] {
+    const char *e = FDNN_TUNE_ENV("FDNN_CHAIN_TILE");
+    return e ? std::atoi(e) : 0;
+  }();
+  if (forced == 256 || forced == 320) return forced;
   // 320-frame tiles unless the padding they add is worth more than their better operand reuse
   const int pad320 = (n + 319) / 320 * 320 - n, pad256 = (n + 255) / 256 * 256 - n;
   return pad256 + 64 < pad320 ? 256 : 320;

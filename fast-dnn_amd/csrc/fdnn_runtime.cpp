@@ -521,6 +521,10 @@ static FuseChain &fuse_chain(int device) {
   static FuseChain chains[64];
   return chains[device & 63];
 }
+// REQUIREMENT (advisor, round 4): whoever owns a stream that stream_is_durable() answers true for -- a context's own stream,
+// a scoring loop's -- must call this before destroying it (destroy_ctx and fdnn_server_free do): the chain keeps the raw
+// handle of the stream its last launch went to and records its event there later.  A caller-created stream is never
+// remembered (its record is made at once).
 void fuse_chain_retire_stream(int device, hipStream_t s) {
   FuseChain &fc = fuse_chain(device);
   std::lock_guard<std::mutex> lk(fc.mu);
