@@ -86,6 +86,8 @@ SIGNATURES = {
     "fdnn_server_set_linger_us": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_server_submit_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]),
     "fdnn_server_submit": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_i8p, _c_f32p, C.POINTER(C.c_uint64)]),
+    "fdnn_server_submit_lazy_bits": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_void_p, _c_f32p, C.POINTER(C.c_uint64)]),
+    "fdnn_debug_lazy_expand": (C.c_int, [_c_f32p, _c_f32p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     "fdnn_server_wait": (C.c_int, [C.c_void_p, C.c_uint64]),
     "fdnn_server_drain": (C.c_int, [C.c_void_p]),
     "fdnn_server_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -391,6 +393,27 @@ class ScoringServer:
         _check(lib().fdnn_server_submit(self.handle, x.ctypes.data_as(_c_f32p), x.shape[0],
                                         m.ctypes.data_as(_c_i8p) if m is not None else None, out.ctypes.data_as(_c_f32p), C.byref(t)))
         self._keep[int(t.value)] = (x, m, out)
+        return int(t.value), out
+
+    def submitLazy(self, x, bits, out=None):
+        """The lazy contract through the loop, masks as bits ([n][ceil(output_dim / 64)] uint64, ``formats.pack_mask_bits``):
+        coalesced with the other callers' bit-mask submissions, rows back compacted and rebuilt inside ``out`` by the
+        thread that waits for the ticket -> (ticket, out array)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.ndim != 2 or x.shape[1] != self.dnn.inputDimension():
+            raise ValueError(f"Input vector size {x.shape[-1]} must be equal with network input size {self.dnn.inputDimension()}")
+        O = self.dnn.outputDimension()
+        b = np.ascontiguousarray(bits, dtype=np.uint64)
+        if b.shape != (x.shape[0], (O + 63) // 64):
+            raise ValueError(f"bits must be {x.shape[0]} x {(O + 63) // 64} uint64, got {b.shape}")
+        if out is None:
+            out = np.empty((x.shape[0], O), dtype=np.float32)
+        elif out.dtype != np.float32 or out.shape != (x.shape[0], O) or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous float32 array of shape {(x.shape[0], O)}")
+        t = C.c_uint64()
+        _check(lib().fdnn_server_submit_lazy_bits(self.handle, x.ctypes.data_as(_c_f32p), x.shape[0], C.c_void_p(b.ctypes.data),
+                                                  out.ctypes.data_as(_c_f32p), C.byref(t)))
+        self._keep[int(t.value)] = (x, b, out)
         return int(t.value), out
 
     def wait(self, ticket: int) -> None:

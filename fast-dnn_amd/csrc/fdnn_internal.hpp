@@ -149,6 +149,9 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
 // Will run_output scale the soft-max inside the output kernel for such a call (dense, large batch)?  Then there is no
 // scale pass to hide under the next batch's layer 0.
 bool output_will_fuse(fdnn_ctx *c, int count, const int8_t *d_masks);
+// Host half of a compacted lazy return: expands `count` compacted rows sitting in the tail of out[count][O] (fdnn_runtime.cpp).
+void lazy_expand_rows(float *out, int count, size_t O, size_t stride, const uint64_t *bits);
+void lazy_expand_rows_from(float *out, const float *comp, int count, size_t O, size_t stride, const uint64_t *bits);  // rows in a buffer of their own
 // A pass over a very large batch runs as chunks (frames are independent: a chunk is a batch of its own, and the scratch
 // context only has to hold one).  kRoundFrames = 32 frame tiles of 320 = one workgroup per CU in the 2048-wide hidden
 // layers; a chunk is two rounds.  Measured, 125 000 frames (the 8-GPU shard of BASELINE configs[4]), fused soft-max:

@@ -51,6 +51,7 @@ struct Piece {  // one caller's rows inside a coalesced batch
   int row0, rows;  // rows [row0, row0 + rows) of the batch
   bool last;       // the ticket's final piece
   int state = 0;   // 0 batch in flight, 1 rows ready in the slot's pinned buffer, 2 being copied out, 3 done
+  const uint64_t *bits = nullptr;  // lazy submissions with bit masks: the caller's words of these rows (compacted return)
 };
 
 struct TicketState {
@@ -70,7 +71,14 @@ struct Request {
   float *out;
   int n;
   int taken = 0;  // frames already packed into earlier batches
+  const uint64_t *bits = nullptr;  // fdnn_server_submit_lazy_bits: [n][ceil(O / 64)] (then masks is null)
+  int most = 0;                    // ... and the largest number of active nodes in any of its rows (counted by the submitter)
 };
+
+// what a host batch carries: requests of different kinds do not share a batch, except that dense callers may ride in a
+// byte-mask batch (all active)
+enum BatchKind { kDense = 0, kBytes = 1, kBits = 2 };
+inline int kind_of(const Request &r) { return r.bits ? kBits : r.masks ? kBytes : kDense; }
 
 struct Slot {
   fdnn_ctx *ctx = nullptr;
@@ -81,6 +89,11 @@ struct Slot {
   // host submissions (allocated on first use)
   float *h_x = nullptr, *d_out = nullptr;
   int8_t *h_mask = nullptr;
+  uint64_t *h_bits = nullptr;     // bit-mask batches: the batch's words (pinned; first such batch allocates)
+  float *d_comp = nullptr;        // ... its compacted result rows [rows][stride]
+  float *h_comp = nullptr;        // ... and where they land on the host (pinned): ONE transfer per batch, behind the compaction
+  size_t comp_floats = 0;
+  int stride = 0;                 // current batch: floats per compacted row (0: the rows leave whole)
   std::vector<Piece> pieces;
   int frames = 0;
   int pieces_left = 0;            // pieces of the current host batch not copied out yet
@@ -106,6 +119,19 @@ struct fdnn_server {
   std::deque<int> flying;         // slots with a host batch enqueued, in launch order
   std::unordered_map<uint64_t, TicketState> pending;  // host tickets not yet complete (a failed one stays until waited for)
   std::thread packer, finisher;
+  // Staging of the batch being packed (frames / masks into the slot's pinned buffers) is shared with the callers blocked in
+  // fdnn_server_wait: sixteen 100-frame utterances are 4.4 MB of memcpy, half a millisecond on the packer thread alone and
+  // the longest stage of the loop; pieces are handed out one by one under qmu (stage_one).
+  struct StageJob {
+    Slot *sl = nullptr;
+    const std::vector<Request> *taken = nullptr;
+    std::vector<int> row0;
+    int kind = 0;
+    bool any_mask = false;
+    int next = 0, done = 0, total = 0;
+  } stage;
+  bool staging = false;
+  std::condition_variable stage_cv;
   bool stop = false;
   bool host_ready = false;
   int linger_us = 0;
@@ -136,7 +162,7 @@ int alloc_host_side(fdnn_server *s) {
 // `after` (may be null) is an event the compute must wait for (the batch's H2D copy);
 // returns with `sl.done` recorded behind the last kernel.
 int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_t *d_masks, float *d_out, hipEvent_t after,
-                  hipStream_t *last_stream) {
+                  hipStream_t *last_stream, const uint64_t *d_bits = nullptr, float *d_comp = nullptr, int stride = 0) {
   fdnn_ctx *c = sl.ctx;
   c->n = n;
   c->last = -1;
@@ -152,7 +178,7 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
   }();
   const std::vector<std::pair<int, int>> chunks = small ? std::vector<std::pair<int, int>>{} : fdnn::frame_chunks(n);
   bool all_fused = !small;
-  for (const auto &ch : chunks) all_fused = all_fused && fdnn::output_will_fuse(c, ch.second, d_masks);  // (a short tail chunk may take the unfused kernels)
+  for (const auto &ch : chunks) all_fused = all_fused && (d_bits || fdnn::output_will_fuse(c, ch.second, d_masks));  // (a short tail chunk may take the unfused kernels)
   c->l0_chain_only = !small && overlap && !all_fused;  // see fdnn_ctx: an overlapped scale pass needs room beside layer 0
   hipStream_t cs = small ? sl.stream : s->s_main;
   if (after) HIP_TRY(hipStreamWaitEvent(cs, after, 0));
@@ -161,13 +187,13 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
   hipStream_t end = cs;
   if (small) {
     rc = fdnn::run_hidden(c, d_x, cs, nullptr);
-    if (!rc) rc = fdnn::run_output(c, 0, n, d_masks, d_out, cs, nullptr);
+    if (!rc) rc = fdnn::run_output(c, 0, n, d_masks, d_out, cs, nullptr, nullptr, nullptr, nullptr, d_bits);
   } else {
     // very large batches go chunk by chunk (fdnn::frame_chunks), and the chunks overlap like batches do: chunk j's
     // scale pass runs on the tail stream under chunk j+1's layer 0.  One context serves all chunks, so the compute
     // stream may not overwrite the soft-max partial sums (chunk j+1's output GEMM) before chunk j's scale pass has
     // read them: it waits for `tail_done` there.
-    const size_t D = size_t(s->m->hm.hdr.in_dim), O = size_t(s->m->hm.hdr.out_dim);
+    const size_t D = size_t(s->m->hm.hdr.in_dim), O = size_t(s->m->hm.hdr.out_dim), wpr = (O + 63) / 64;
     bool first = true;
     for (size_t ci = 0; ci < chunks.size(); ++ci) {
       const auto &ch = chunks[ci];
@@ -176,7 +202,8 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
       if (rc) break;
       if (!first && overlap) HIP_TRY(hipStreamWaitEvent(cs, sl.tail_done, 0));
       rc = fdnn::run_output(c, 0, ch.second, d_masks ? d_masks + size_t(ch.first) * O : nullptr, d_out + size_t(ch.first) * O, cs,
-                            nullptr, nullptr, overlap ? s->s_tail : nullptr, overlap ? sl.gemm_done : nullptr);
+                            nullptr, nullptr, overlap ? s->s_tail : nullptr, overlap ? sl.gemm_done : nullptr,
+                            d_bits ? d_bits + size_t(ch.first) * wpr : nullptr);
       if (rc) break;
       // (without the overlap everything is on the compute stream, in order; a record is 3-4 us of queue time)
       if (overlap && ci + 1 < chunks.size()) HIP_TRY(hipEventRecord(sl.tail_done, s->s_tail));
@@ -185,6 +212,9 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
     c->n = n;
     end = overlap ? s->s_tail : cs;
   }
+  // bit-mask host batches: the rows compacted (active probabilities + one value per frame) for the trip over PCIe
+  if (!rc && d_bits && d_comp && stride > 0)
+    fdnn::launch_lazy_compact(d_out, d_bits, d_comp, n, s->m->hm.hdr.out_dim, stride, end);
   fdnn::ctx_leave(c, end);
   if (rc) return rc;
   *last_stream = end;
@@ -220,7 +250,14 @@ void copy_ready_pieces(fdnn_server *s, std::unique_lock<std::mutex> &lk, Slot &s
     // straight from the slot's device buffer into the caller's memory, on the copying thread's own stream: no pinned
     // bounce buffer and no second pass over the 32 KB per frame
     hipError_t ce;
-    {
+    const size_t stride = size_t(sl.stride);  // (stable while the slot is in flight)
+    if (job.bits && stride > 0) {
+      // lazy rows, compacted: the batch's rows arrived in the slot's pinned buffer with the batch (one transfer, enqueued
+      // behind the compaction); THIS thread -- the caller's own, normally, so that sixteen callers work side by side --
+      // expands its rows into the caller's block (fdnn::lazy_expand_rows_from)
+      ce = hipSuccess;
+      fdnn::lazy_expand_rows_from(job.out, sl.h_comp + size_t(job.row0) * stride, job.rows, O, stride, job.bits);
+    } else {
       DeviceGuard dg(s->m->device);
       ce = hipMemcpyAsync(job.out, sl.d_out + size_t(job.row0) * O, sizeof(float) * size_t(job.rows) * O, hipMemcpyDeviceToHost,
                           hipStreamPerThread);
@@ -247,6 +284,32 @@ void copy_ready_pieces(fdnn_server *s, std::unique_lock<std::mutex> &lk, Slot &s
     }
     if (finished || ce != hipSuccess) s->done_cv.notify_all();
   }
+}
+
+// One request's frames (and masks) into the slot's pinned buffers, by whoever asks: the packer, or a caller waiting for its
+// ticket.  Call with qmu held (dropped around the copies); false = nothing left to hand out.
+bool stage_one(fdnn_server *s, std::unique_lock<std::mutex> &lk) {
+  if (!s->staging || s->stage.next >= s->stage.total) return false;
+  const int i = s->stage.next++;
+  Slot &sl = *s->stage.sl;
+  const Request r = (*s->stage.taken)[size_t(i)];
+  const int r0 = s->stage.row0[size_t(i)], kind = s->stage.kind;
+  const bool any_mask = s->stage.any_mask;
+  lk.unlock();
+  const fdnn::BlobHeader &h = s->m->hm.hdr;
+  const size_t D = size_t(h.in_dim), O = size_t(h.out_dim), wpr = (O + 63) / 64;
+  std::memcpy(sl.h_x + size_t(r0) * D, r.x + size_t(r.taken) * D, sizeof(float) * size_t(r.n) * D);
+  if (kind == kBits && sl.h_bits) {  // (only bit-mask requests are in such a batch)
+    std::memcpy(sl.h_bits + size_t(r0) * wpr, r.bits + size_t(r.taken) * wpr, sizeof(uint64_t) * size_t(r.n) * wpr);
+  } else if (any_mask) {
+    if (r.masks)
+      std::memcpy(sl.h_mask + size_t(r0) * O, r.masks + size_t(r.taken) * O, size_t(r.n) * O);
+    else
+      std::memset(sl.h_mask + size_t(r0) * O, 1, size_t(r.n) * O);  // dense caller inside a lazy batch: all active
+  }
+  lk.lock();
+  if (++s->stage.done == s->stage.total) s->stage_cv.notify_all();
+  return true;
 }
 
 // Packs queued requests into batches and enqueues them.
@@ -287,10 +350,22 @@ void packer_loop(fdnn_server *s) {
     // take requests, whole or in part, until the batch is full
     std::vector<Request> taken;
     sl.pieces.clear();
-    int rows = 0;
+    int rows = 0, most = 0;
     bool any_mask = false;
+    const size_t wpr = (O + 63) / 64;
+    // a batch carries bit-mask requests only, or none (dense and byte-mask callers share batches as before: the dense rows
+    // of such a batch get all-active masks); a request of the other sort waits for the next batch
+    int kind = kDense;
     while (!s->queue.empty() && rows < s->max_frames) {
       Request &r = s->queue.front();
+      const int rk = kind_of(r);
+      if (rows == 0)
+        kind = rk;
+      else if ((rk == kBits) != (kind == kBits))
+        break;
+      else if (rk == kBytes)
+        kind = kBytes;
+      most = std::max(most, r.most);
       const int take = std::min(r.n - r.taken, s->max_frames - rows);
       Request part = r;
       part.taken = r.taken;
@@ -299,7 +374,7 @@ void packer_loop(fdnn_server *s) {
       any_mask |= r.masks != nullptr;
       r.taken += take;
       const bool last = r.taken == r.n;
-      sl.pieces.push_back(Piece{r.ticket, r.out + size_t(part.taken) * O, rows, take, last, 0});
+      sl.pieces.push_back(Piece{r.ticket, r.out + size_t(part.taken) * O, rows, take, last, 0, r.bits ? r.bits + size_t(part.taken) * wpr : nullptr});
       {
         auto it = s->pending.find(r.ticket);
         if (it != s->pending.end()) {
@@ -311,38 +386,69 @@ void packer_loop(fdnn_server *s) {
       if (last) s->queue.pop_front();
     }
     sl.frames = rows;
+    // compacted return (bit-mask batches): worth it while a row is at most 3/4 active nodes
+    const size_t stride = size_t(most) + 1;
+    sl.stride = kind == kBits && stride * 4 <= O * 3 ? int(stride) : 0;
     sl.pieces_left = int(sl.pieces.size());
     sl.in_flight = true;
     s->host_next_slot = uint64_t(si) + 1;
     lk.unlock();
 
     // stage (pinned), copy, compute, copy back -- all asynchronous from here
-    int r0 = 0;
-    for (const Request &r : taken) {
-      std::memcpy(sl.h_x + size_t(r0) * D, r.x + size_t(r.taken) * D, sizeof(float) * size_t(r.n) * D);
-      if (any_mask) {
-        if (r.masks)
-          std::memcpy(sl.h_mask + size_t(r0) * O, r.masks + size_t(r.taken) * O, size_t(r.n) * O);
-        else
-          std::memset(sl.h_mask + size_t(r0) * O, 1, size_t(r.n) * O);  // dense caller inside a lazy batch: all active
+    hipError_t e = hipSuccess;
+    if (kind == kBits) {  // staging of the first bit-mask batch of this slot
+      if (!sl.h_bits) e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_bits), sizeof(uint64_t) * size_t(s->max_frames) * wpr, hipHostMallocDefault);
+      const size_t need = size_t(s->max_frames) * (O * 3 / 4 + 1);
+      if (e == hipSuccess && sl.stride > 0 && sl.comp_floats < need) {
+        e = hipMalloc(reinterpret_cast<void **>(&sl.d_comp), sizeof(float) * need);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_comp), sizeof(float) * need, hipHostMallocDefault);
+        if (e == hipSuccess) sl.comp_floats = need;
       }
-      r0 += r.n;
+    }
+    if (e == hipSuccess) {  // the pieces' copies: this thread and whoever is blocked in fdnn_server_wait, piece by piece
+      lk.lock();
+      s->stage.sl = &sl;
+      s->stage.taken = &taken;
+      s->stage.row0.clear();
+      int r0 = 0;
+      for (const Request &r : taken) {
+        s->stage.row0.push_back(r0);
+        r0 += r.n;
+      }
+      s->stage.kind = kind;
+      s->stage.any_mask = any_mask;
+      s->stage.next = s->stage.done = 0;
+      s->stage.total = int(taken.size());
+      s->staging = true;
+      if (taken.size() > 1) s->done_cv.notify_all();
+      while (stage_one(s, lk)) {
+      }
+      s->stage_cv.wait(lk, [&] { return s->stage.done == s->stage.total; });
+      s->staging = false;
+      lk.unlock();
     }
     int rc = FDNN_OK;
-    hipError_t e = hipSuccess;
-    {
+    if (e == hipSuccess) {
       std::lock_guard<std::mutex> order(s->mu);  // launch order against device submissions
       fdnn_ctx *c = sl.ctx;
+      const bool bits = kind == kBits;
       e = hipMemcpyAsync(c->d_x, sl.h_x, sizeof(float) * size_t(rows) * D, hipMemcpyHostToDevice, sl.stream);
-      if (e == hipSuccess && any_mask) e = hipMemcpyAsync(c->d_mask, sl.h_mask, size_t(rows) * O, hipMemcpyHostToDevice, sl.stream);
+      if (e == hipSuccess && bits)
+        e = hipMemcpyAsync(c->d_mask_bits, sl.h_bits, sizeof(uint64_t) * size_t(rows) * wpr, hipMemcpyHostToDevice, sl.stream);
+      else if (e == hipSuccess && any_mask)
+        e = hipMemcpyAsync(c->d_mask, sl.h_mask, size_t(rows) * O, hipMemcpyHostToDevice, sl.stream);
       if (e == hipSuccess) e = hipEventRecord(sl.staged, sl.stream);
       hipStream_t last = sl.stream;
-      if (e == hipSuccess) rc = enqueue_batch(s, sl, c->d_x, rows, any_mask ? c->d_mask : nullptr, sl.d_out, sl.staged, &last);
+      if (e == hipSuccess)
+        rc = enqueue_batch(s, sl, c->d_x, rows, !bits && any_mask ? c->d_mask : nullptr, sl.d_out, sl.staged, &last, bits ? c->d_mask_bits : nullptr,
+                           sl.d_comp, sl.stride);
       if (e == hipSuccess && !rc) {
         if (last != sl.stream) {  // results leave on the slot's stream, behind the tail stream's scale pass
           e = hipEventRecord(sl.gemm_done, last);  // (gemm_done is free again: the scale pass already waits on its earlier record)
           if (e == hipSuccess) e = hipStreamWaitEvent(sl.stream, sl.gemm_done, 0);
         }
+        if (e == hipSuccess && bits && sl.stride > 0)  // compacted rows: to the host with the batch
+          e = hipMemcpyAsync(sl.h_comp, sl.d_comp, sizeof(float) * size_t(rows) * size_t(sl.stride), hipMemcpyDeviceToHost, sl.stream);
         if (e == hipSuccess) e = hipEventRecord(sl.done, sl.stream);  // the rows leave later, piece by piece (copy_ready_pieces)
       }
     }
@@ -503,6 +609,9 @@ void fdnn_server_free(fdnn_server *s) {
     if (sl.ctx) fdnn::destroy_ctx(sl.ctx);
     if (sl.h_x) hipHostFree(sl.h_x);
     if (sl.h_mask) hipHostFree(sl.h_mask);
+    if (sl.h_bits) hipHostFree(sl.h_bits);
+    if (sl.d_comp) hipFree(sl.d_comp);
+    if (sl.h_comp) hipHostFree(sl.h_comp);
     if (sl.d_out) hipFree(sl.d_out);
     if (sl.gemm_done) hipEventDestroy(sl.gemm_done);
     if (sl.tail_done) hipEventDestroy(sl.tail_done);
@@ -587,6 +696,42 @@ int fdnn_server_submit(fdnn_server *s, const float *x, int n, const int8_t *mask
   return FDNN_OK;
 }
 
+int fdnn_server_submit_lazy_bits(fdnn_server *s, const float *x, int n, const uint64_t *bits, float *out, uint64_t *ticket) {
+  if (!s || !ticket) return fail(FDNN_E_ARG, "null argument");
+  if (n <= 0) return fail(FDNN_E_ARG, "frame count must be positive");
+  if (!x || !out || !bits) return fail(FDNN_E_ARG, "null buffer");
+  int rc = start_host_side(s);
+  if (rc) return rc;
+  // the widest row of the request, counted here (on the caller's thread) for the batch's compacted row length
+  const size_t O = size_t(s->m->hm.hdr.out_dim), wpr = (O + 63) / 64;
+  const uint64_t tail_mask = (O & 63) ? ((uint64_t(1) << (O & 63)) - 1) : ~uint64_t(0);
+  int most = 0;
+  for (int f = 0; f < n; ++f) {
+    const uint64_t *row = bits + size_t(f) * wpr;
+    int k = 0;
+    for (size_t w = 0; w + 1 < wpr; ++w) k += __builtin_popcountll(row[w]);
+    k += __builtin_popcountll(row[wpr - 1] & tail_mask);
+    most = std::max(most, k);
+  }
+  uint64_t t;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    t = s->next_ticket++;
+  }
+  {
+    std::lock_guard<std::mutex> lk(s->qmu);
+    s->pending.emplace(t, TicketState{});
+    Request r{t, x, nullptr, out, n, 0};
+    r.bits = bits;
+    r.most = most;
+    s->queue.push_back(r);
+  }
+  s->n_requests++;
+  s->qcv.notify_all();
+  *ticket = t;
+  return FDNN_OK;
+}
+
 int fdnn_server_wait(fdnn_server *s, uint64_t ticket) {
   if (!s) return fail(FDNN_E_ARG, "null argument");
   {  // a host ticket?
@@ -610,7 +755,7 @@ int fdnn_server_wait(fdnn_server *s, uint64_t ticket) {
               break;
             }
         }
-        if (!copied) s->done_cv.wait(lk);
+        if (!copied && !stage_one(s, lk)) s->done_cv.wait(lk);  // (idle hands: help the packer stage the next batch)
       }
     }
   }

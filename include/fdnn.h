@@ -195,6 +195,12 @@ FDNN_API int fdnn_server_set_linger_us(fdnn_server *s, int microseconds);
 FDNN_API int fdnn_server_submit_device(fdnn_server *s, const float *d_x, int n, const int8_t *d_masks, float *d_out,
                                        uint64_t *ticket);
 FDNN_API int fdnn_server_submit(fdnn_server *s, const float *x, int n, const int8_t *masks, float *out, uint64_t *ticket);
+/* The lazy contract through the loop with the masks as BITS (bits [n][ceil(output_dim / 64)], bit b of word w = node
+ * 64 w + b, as fdnn_calculate_lazy_bits): bit-mask submissions are coalesced with one another, scored once, and come back
+ * COMPACTED -- the active nodes' probabilities and one value per frame over PCIe, each caller's rows rebuilt inside its
+ * own `out` by the thread that waits for the ticket.  x / bits / out must stay valid until the ticket completes.
+ * (LazyContext.calculateUntilOutput + calculateForOutputNodes per frame, QuantizedDnn.java:72-107, for many callers.) */
+FDNN_API int fdnn_server_submit_lazy_bits(fdnn_server *s, const float *x, int n, const uint64_t *bits, float *out, uint64_t *ticket);
 FDNN_API int fdnn_server_wait(fdnn_server *s, uint64_t ticket);
 FDNN_API int fdnn_server_drain(fdnn_server *s);
 FDNN_API int fdnn_server_stats(fdnn_server *s, uint64_t *batches, uint64_t *frames, uint64_t *requests,
@@ -274,6 +280,13 @@ FDNN_API int fdnn_debug_set_l0_kernel(fdnn_model *m, int kind);
  * process on the GPU selects), 1 = inside the output kernel wherever the shape allows, -1 = the default rule.  Results are
  * bit-identical (one tree order for the row total everywhere).  SoftMax::apply, dnn.cc:534-544. */
 FDNN_API int fdnn_debug_set_fuse(int mode);
+
+/* Tests only, host code, no device needed: the host half of a compacted lazy return (what fdnn_calculate_lazy_bits and
+ * the scoring loop run on the caller's thread).  comp [count][stride] = per row its inactive value, then its active nodes'
+ * values in node order; bits [count][ceil(O / 64)]; out [count][O].  mode 0: the library's choice (AVX-512 expanding loads
+ * where the CPU has them), 1: the scalar form, 2: comp copied into the tail of out first (the in-place form of the
+ * one-call entry).  LazyOutputActivations' row layout, dnn.cc:366-369, :389. */
+FDNN_API int fdnn_debug_lazy_expand(float *out, const float *comp, int count, int O, int stride, const uint64_t *bits, int mode);
 
 /* Tests only: cap the per-launch list of flagged layer-0 outputs (int8 screening) of contexts created AFTER the call at
  * `cap` entries (0 = the default, 1/16 of the outputs), so that a small batch overflows it: tiles that no longer fit take

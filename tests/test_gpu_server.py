@@ -281,3 +281,83 @@ def test_create_and_free_cycles_return_device_memory(mid_model_path):
     torch.cuda.empty_cache()
     free1, _total = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, f"{(free0 - free1) >> 20} MiB of device memory did not come back after 25 create/free cycles"
+
+
+def test_lazy_bit_mask_submissions_are_coalesced_and_come_back_compacted(mid_model_path):
+    """fdnn_server_submit_lazy_bits: LazyContext's contract (QuantizedDnn.java:72-107, dnn.cc:355-392) for many callers --
+    8 threads x ragged utterances with bit masks, dense callers in between (they never share a bit-mask batch), an
+    utterance longer than a batch (its pieces come back compacted one by one), a nearly-all-active mask (its batch
+    leaves whole) and an all-inactive one.  Every row equals the same utterance through the one-call lazy entry bit for
+    bit, and the oracle's lazy rows."""
+    dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+    orc = Oracle(mid_model_path)
+    O = dnn.outputDimension()
+    lens = [100, 37, 1, 250, 100, 1300, 64, 100, 2, 511]
+    utts = [F.synth_features(n, 432, seed=500 + i) for i, n in enumerate(lens)]
+    masks = [F.generate_masks(n, O, 0.4, 0.03, seed=20 + i) for i, n in enumerate(lens)]
+    masks[2][:] = 0             # no active node at all
+    masks[6][:] = 1
+    masks[6][:, ::17] = 0       # ~94 % active: this batch is not worth compacting
+    masks[4][3] = 1             # one all-active row inside an ordinary utterance
+    bits = [F.pack_mask_bits(m) for m in masks]
+    dense_ids = {7, 8}          # these two are submitted dense
+    alone = [dnn.calculate(x) if i in dense_ids else dnn.calculateLazy(x, bits=bits[i]) for i, x in enumerate(utts)]
+    for i in (0, 2, 5):
+        assert np.abs(alone[i] - orc.lazy(utts[i], masks[i])).max() <= TIGHT
+    srv = api.ScoringServer(dnn, max_frames=1024, depth=3, linger_us=200)
+    results, errors = [], []
+    lock = threading.Lock()
+
+    def worker(w):
+        try:
+            for j in range(len(utts)):
+                i = (j + w) % len(utts)
+                out = np.full((lens[i], O), -7.0, dtype=np.float32)
+                t, _ = srv.submit(utts[i], out=out) if i in dense_ids else srv.submitLazy(utts[i], bits[i], out=out)
+                srv.wait(t)
+                with lock:
+                    results.append((i, out))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(w,)) for w in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    assert len(results) == 8 * len(utts)
+    for i, out in results:
+        assert np.array_equal(out, alone[i]), i
+    st = srv.stats()
+    assert st["coalesced_requests"] > 0
+    with pytest.raises(api.FdnnError):
+        api._check(api.lib().fdnn_server_submit_lazy_bits(srv.handle, utts[0].ctypes.data_as(api._c_f32p), 100, None,
+                                                          results[0][1].ctypes.data_as(api._c_f32p), None))
+    srv.close()
+    dnn.delete()
+
+
+def test_one_call_lazy_through_the_model_batcher(mid_model_path):
+    """fdnn_model_enable_batcher also carries the one-call lazy entry (the JNI extension calculateLazyBatch): 8 threads,
+    lazy and dense calls mixed, same bits as without the batcher."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    O = 1000
+    xs = [F.synth_features(20 + 17 * i, seed=330 + i) for i in range(10)]
+    ms = [F.generate_masks(len(x), O, 0.4, 0.03, seed=40 + i) for i, x in enumerate(xs)]
+    plain = api.QuantizedDnn.loadFromFile(mid_model_path)
+    want = [plain.calculateLazy(x, masks=m) if i % 3 else plain.calculate(x) for i, (x, m) in enumerate(zip(xs, ms))]
+    plain.delete()
+    dnn = api.QuantizedDnn.loadFromFile(mid_model_path)
+    dnn.enableBatcher(2048, 2, 100)
+
+    def one(k):
+        i = k % 10
+        return dnn.calculateLazy(xs[i], masks=ms[i]) if i % 3 else dnn.calculate(xs[i])
+
+    with ThreadPoolExecutor(8) as ex:
+        got = list(ex.map(one, range(80)))
+    for k, g in enumerate(got):
+        assert np.array_equal(g, want[k % 10]), k
+    dnn.delete()

@@ -185,3 +185,35 @@ def test_layer_with_millions_of_saturating_pairs_loads(tmp_path):
     assert hm.risky_pairs(1) == 2048 * 1024 > (1 << 20)
     assert hm.risky_pairs(1) == Oracle(p).risky_pairs(1)
     assert api.host_blob_check(hm.blob())["n_affine"] == 4
+
+
+@pytest.mark.parametrize("O", [8000, 1000, 77, 64])
+def test_compacted_lazy_rows_expand_to_the_reference_layout(O):
+    """The host half of a compacted lazy return: every inactive node of a row reads the row's one inactive value
+    (exp(0) / total, dnn.cc:366-369, :389), the active ones their own -- the library's expanding-load form, its scalar
+    form and the in-place form (compacted rows in the tail of the caller's block) against plain numpy indexing."""
+    import ctypes as C
+
+    rng = np.random.default_rng(O)
+    n = 37
+    masks = (rng.random((n, O)) < 0.4).astype(np.int8)
+    masks[0] = 0
+    masks[1] = 1
+    masks[2, : O // 2] = 1
+    masks[3, -1] = 1
+    masks[4, -1] = 0
+    bits = F.pack_mask_bits(masks)
+    most = int(masks.sum(1).max())
+    for stride in (most + 1, min(O + 1, most + 9)):
+        comp = rng.random((n, stride), dtype=np.float32)
+        want = np.empty((n, O), dtype=np.float32)
+        for f in range(n):
+            want[f] = comp[f, 0]
+            want[f, masks[f] != 0] = comp[f, 1 : 1 + int(masks[f].sum())]
+        for mode in (0, 1, 2):
+            if mode == 2 and stride > O:
+                continue
+            out = np.full((n, O), -3.0, dtype=np.float32)
+            api._check(api.lib().fdnn_debug_lazy_expand(out.ctypes.data_as(api._c_f32p), comp.ctypes.data_as(api._c_f32p), n, O, stride,
+                                                        C.c_void_p(bits.ctypes.data), mode))
+            assert np.array_equal(out, want), (O, stride, mode)

@@ -5,13 +5,17 @@
 //         server   = fdnn_server_submit + fdnn_server_wait (coalesced host submissions)
 //         batcher  = fdnn_calculate on a model with fdnn_model_enable_batcher
 //         fresh    = percall into a newly allocated, zero-filled result block per call (the reference shim's shape)
+//         lazy       = fdnn_calculate_lazy_bits per utterance (one-call lazy scoring, 40 % of the nodes active per frame)
+//         lazyserver = fdnn_server_submit_lazy_bits + fdnn_server_wait (bit-mask utterances coalesced, rows back compacted)
 // Prints one JSON line.  Build: see tools/serve_bench.sh.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -34,7 +38,8 @@ int main(int argc, char **argv) {
   }
   const int D = fdnn_model_input_dim(m), O = fdnn_model_output_dim(m);
   fdnn_server *srv = nullptr;
-  if (mode == "server" && fdnn_server_create(m, max_frames, depth, &srv)) {
+  const bool lazy = mode == "lazy" || mode == "lazyserver";
+  if ((mode == "server" || mode == "lazyserver") && fdnn_server_create(m, max_frames, depth, &srv)) {
     std::fprintf(stderr, "server: %s\n", fdnn_last_error());
     return 1;
   }
@@ -51,12 +56,42 @@ int main(int argc, char **argv) {
     for (float &v : xs[size_t(t)]) v = nd(rng);
     outs[size_t(t)].assign(size_t(F) * O, 0.0f);  // resident, like a reused JVM float[]
   }
+  // lazy modes: per thread, masks with 40 % of the nodes active in every frame and 3 % churn from frame to frame
+  // (FuncTest.java:121-154's statistics), as bits
+  const size_t wpr = (size_t(O) + 63) / 64;
+  std::vector<std::vector<uint64_t>> bits(static_cast<size_t>(T));
+  if (lazy) {
+    for (int t = 0; t < T; ++t) {
+      std::vector<char> on(size_t(O), 0);
+      std::vector<int> perm(static_cast<size_t>(O));
+      for (int i = 0; i < O; ++i) perm[size_t(i)] = i;
+      std::shuffle(perm.begin(), perm.end(), rng);
+      const int active = int(O * 0.40), churn = int(O * 0.03);
+      for (int i = 0; i < active; ++i) on[size_t(perm[size_t(i)])] = 1;
+      bits[size_t(t)].assign(size_t(F) * wpr, 0);
+      std::uniform_int_distribution<int> pick(0, O - 1);
+      for (int f = 0; f < F; ++f) {
+        if (f) {
+          for (int c = 0, done = 0; done < churn && c < 100 * churn; ++c) { const int i = pick(rng); if (!on[size_t(i)]) { on[size_t(i)] = 1; ++done; } }
+          for (int c = 0, done = 0; done < churn && c < 100 * churn; ++c) { const int i = pick(rng); if (on[size_t(i)]) { on[size_t(i)] = 0; ++done; } }
+        }
+        for (int i = 0; i < O; ++i)
+          if (on[size_t(i)]) bits[size_t(t)][size_t(f) * wpr + size_t(i >> 6)] |= uint64_t(1) << (i & 63);
+      }
+    }
+  }
   std::atomic<int> failed{0};
   static thread_local float sink = 0.0f;
   auto body = [&](int t, int utts) {
     for (int u = 0; u < utts; ++u) {
       int rc;
-      if (srv) {
+      if (srv && lazy) {
+        uint64_t ticket = 0;
+        rc = fdnn_server_submit_lazy_bits(srv, xs[size_t(t)].data(), F, bits[size_t(t)].data(), outs[size_t(t)].data(), &ticket);
+        if (!rc) rc = fdnn_server_wait(srv, ticket);
+      } else if (lazy) {
+        rc = fdnn_calculate_lazy_bits(m, xs[size_t(t)].data(), F, D, bits[size_t(t)].data(), outs[size_t(t)].data());
+      } else if (srv) {
         uint64_t ticket = 0;
         rc = fdnn_server_submit(srv, xs[size_t(t)].data(), F, nullptr, outs[size_t(t)].data(), &ticket);
         if (!rc) rc = fdnn_server_wait(srv, ticket);
