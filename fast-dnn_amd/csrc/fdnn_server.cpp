@@ -88,6 +88,9 @@ struct Slot {
   bool used = false;              // `done` has been recorded at least once
   // host submissions (allocated on first use)
   float *h_x = nullptr, *d_out = nullptr;
+  float *h_out = nullptr;         // whole-row batches of several callers: the rows' landing area on the host (pinned; ONE transfer
+  size_t h_out_floats = 0;        // per batch at the link's rate instead of one pageable copy per caller), allocated on first use
+  bool rows_on_host = false;      // current batch: its rows have been brought to h_out
   int8_t *h_mask = nullptr;
   uint64_t *h_bits = nullptr;     // bit-mask batches: the batch's words (pinned; first such batch allocates)
   float *d_comp = nullptr;        // ... its compacted result rows [rows][stride]
@@ -257,6 +260,10 @@ void copy_ready_pieces(fdnn_server *s, std::unique_lock<std::mutex> &lk, Slot &s
       // expands its rows into the caller's block (fdnn::lazy_expand_rows_from)
       ce = hipSuccess;
       fdnn::lazy_expand_rows_from(job.out, sl.h_comp + size_t(job.row0) * stride, job.rows, O, stride, job.bits);
+    } else if (sl.rows_on_host) {
+      // whole rows of a coalesced batch: they came to the slot's pinned buffer with the batch; this thread moves its own
+      ce = hipSuccess;
+      std::memcpy(job.out, sl.h_out + size_t(job.row0) * O, sizeof(float) * size_t(job.rows) * O);
     } else {
       DeviceGuard dg(s->m->device);
       ce = hipMemcpyAsync(job.out, sl.d_out + size_t(job.row0) * O, sizeof(float) * size_t(job.rows) * O, hipMemcpyDeviceToHost,
@@ -396,6 +403,19 @@ void packer_loop(fdnn_server *s) {
 
     // stage (pinned), copy, compute, copy back -- all asynchronous from here
     hipError_t e = hipSuccess;
+    // Whole rows of a batch that several callers share (and that is not too large to pin: 1 GB of pinned memory per slot at
+    // most) go to the host in one transfer; a single caller's batch is copied by that caller straight into its memory.
+    const bool compacted = kind == kBits && sl.stride > 0;
+    sl.rows_on_host = false;
+    if (!compacted && taken.size() > 1 && size_t(s->max_frames) * O * sizeof(float) <= (size_t(1) << 30)) {
+      const size_t need = size_t(s->max_frames) * O;
+      if (sl.h_out_floats < need) {
+        e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_out), sizeof(float) * need, hipHostMallocDefault);
+        if (e == hipSuccess) sl.h_out_floats = need;
+      }
+      sl.rows_on_host = e == hipSuccess;
+      e = hipSuccess;  // (no pinned memory to be had: the per-caller copies as before)
+    }
     if (kind == kBits) {  // staging of the first bit-mask batch of this slot
       if (!sl.h_bits) e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_bits), sizeof(uint64_t) * size_t(s->max_frames) * wpr, hipHostMallocDefault);
       const size_t need = size_t(s->max_frames) * (O * 3 / 4 + 1);
@@ -449,6 +469,8 @@ void packer_loop(fdnn_server *s) {
         }
         if (e == hipSuccess && bits && sl.stride > 0)  // compacted rows: to the host with the batch
           e = hipMemcpyAsync(sl.h_comp, sl.d_comp, sizeof(float) * size_t(rows) * size_t(sl.stride), hipMemcpyDeviceToHost, sl.stream);
+        else if (e == hipSuccess && sl.rows_on_host)
+          e = hipMemcpyAsync(sl.h_out, sl.d_out, sizeof(float) * size_t(rows) * O, hipMemcpyDeviceToHost, sl.stream);
         if (e == hipSuccess) e = hipEventRecord(sl.done, sl.stream);  // the rows leave later, piece by piece (copy_ready_pieces)
       }
     }
@@ -612,6 +634,7 @@ void fdnn_server_free(fdnn_server *s) {
     if (sl.h_bits) hipHostFree(sl.h_bits);
     if (sl.d_comp) hipFree(sl.d_comp);
     if (sl.h_comp) hipHostFree(sl.h_comp);
+    if (sl.h_out) hipHostFree(sl.h_out);
     if (sl.d_out) hipFree(sl.d_out);
     if (sl.gemm_done) hipEventDestroy(sl.gemm_done);
     if (sl.tail_done) hipEventDestroy(sl.tail_done);

@@ -81,7 +81,7 @@ int main(int argc, char **argv) {
     }
   }
   std::atomic<int> failed{0};
-  static thread_local float sink = 0.0f;
+  static thread_local volatile float sink = 0.0f;
   auto body = [&](int t, int utts) {
     for (int u = 0; u < utts; ++u) {
       int rc;
@@ -98,7 +98,7 @@ int main(int argc, char **argv) {
       } else if (mode == "fresh") {  // the reference shim's shape: a new zero-filled result block per call (jni_dnn.cc:49-57)
         std::vector<float> fresh(size_t(F) * O);
         rc = fdnn_calculate(m, xs[size_t(t)].data(), F, D, 10, fresh.data());
-        sink += fresh[size_t(u) % fresh.size()];
+        sink = sink + fresh[size_t(u) % fresh.size()];
       } else {
         rc = fdnn_calculate(m, xs[size_t(t)].data(), F, D, 10, outs[size_t(t)].data());
       }
