@@ -103,6 +103,7 @@ struct fdnn_ctx {
   int chain_clk_cap = 0;
   float *d_l0_dbg_t = nullptr, *d_l0_dbg_dd = nullptr;  // fdnn_debug_layer0_screen only: the int8 screening's t~ and Dd per output
   uint64_t *d_mask_bits = nullptr;  // [n][ceil(O/64)] the batched lazy call's mask as bits (launch_mask_pack)
+  bool mask_bits_packed = false;    // run_output has packed the current call's byte masks into d_mask_bits
   float *d_comp = nullptr;          // host lazy batches: compacted result rows (allocated on first use)
   size_t comp_floats = 0;
   int last = -1;                  // d_act index holding the last hidden layer, -1 = not computed

@@ -572,6 +572,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
     fdnn::launch_mask_pack(d_masks, c->d_mask_bits, count, d.rows, s);
     g.mask_bits = c->d_mask_bits;
     g.mask_wpr = (d.rows + 63) / 64;
+    c->mask_bits_packed = true;  // (fdnn_ctx_lazy_output_batch needs the same bits for its compacted return: not twice)
   }
   g.tap_acc = taps ? taps->acc_out : nullptr;
   g.tap_logit = taps ? taps->logits : nullptr;
@@ -1220,6 +1221,7 @@ int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *
     return FDNN_OK;
   }
   HIP_TRY(hipMemcpyAsync(c->d_mask, masks, size_t(count) * O, hipMemcpyHostToDevice, c->stream));
+  c->mask_bits_packed = false;
   int rc = run_output(c, first, count, c->d_mask, c->d_out, c->stream, nullptr);
   if (!rc) {
     // the same masks as bits, for the compacted return (lazy_copy_out): on the host while the GPU computes, on the device
@@ -1227,7 +1229,7 @@ int fdnn_ctx_lazy_output_batch(fdnn_ctx *c, int first, int count, const int8_t *
     const size_t wpr = (O + 63) / 64;
     std::vector<uint64_t> hb(size_t(count) * wpr, 0);
     pack_mask_rows(masks, count, O, hb.data());
-    fdnn::launch_mask_pack(c->d_mask, c->d_mask_bits, count, int(O), c->stream);
+    if (!c->mask_bits_packed) fdnn::launch_mask_pack(c->d_mask, c->d_mask_bits, count, int(O), c->stream);  // (a large batch's output kernel has)
     rc = lazy_copy_out(c, count, c->d_mask_bits, hb.data(), out, c->stream);
   }
   ctx_leave(c, c->stream);
