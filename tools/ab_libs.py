@@ -22,6 +22,8 @@ p = "/tmp/fdnn_ab_%s.bin" % mode
 if not os.path.exists(p):
     F.write_model_bin(p + ".tmp", F.synth_net(F.NET_TOPOLOGY, seed=1, mode=mode)); os.replace(p + ".tmp", p)
 dnn = api.QuantizedDnn.loadFromFile(p)
+if os.environ.get("AB_CHAIN_FORCE"):  # 1: the chained hidden layers wherever the shape allows, 0: never
+    api.set_chain(int(os.environ["AB_CHAIN_FORCE"]), 1)
 x = torch.from_numpy(F.synth_features(n, 432, seed=5)).cuda()
 out = torch.empty((n, 8000), dtype=torch.float32, device="cuda")
 s = torch.cuda.current_stream().cuda_stream
@@ -51,13 +53,21 @@ def main():
     ap.add_argument("--mode", default="gauss")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--chain", default=None, help="FDNN_CHAIN for the runs (0: a launch per hidden layer, 1: the default rule)")
+    ap.add_argument("--chain-force", default=None, help="comma list, e.g. 0,1: every library is run once per value (api.set_chain)")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     libs = [l.split("=", 1) if "=" in l else (os.path.basename(l), l) for l in a.libs]
+    if a.chain_force:
+        libs = [(f"{name}/chain{v}", path + "|" + v) for name, path in libs for v in a.chain_force.split(",")]
     res = {name: [] for name, _ in libs}
     for rep in range(a.reps):
         for name, path in libs:
+            force = None
+            if "|" in path:
+                path, force = path.split("|")
             env = dict(os.environ, FDNN_LIB=os.path.abspath(path), AB_ROOT=ROOT, AB_FRAMES=str(a.frames), AB_MODE=a.mode)
+            if force is not None:
+                env["AB_CHAIN_FORCE"] = force
             if a.chain is not None:
                 env["FDNN_CHAIN"] = a.chain
             r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
