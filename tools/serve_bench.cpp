@@ -7,6 +7,8 @@
 //         fresh    = percall into a newly allocated, zero-filled result block per call (the reference shim's shape)
 //         lazy       = fdnn_calculate_lazy_bits per utterance (one-call lazy scoring, 40 % of the nodes active per frame)
 //         lazyserver = fdnn_server_submit_lazy_bits + fdnn_server_wait (bit-mask utterances coalesced, rows back compacted)
+// INFLIGHT=k (environment, server modes): every caller keeps k utterances in flight (k result blocks per thread) instead of
+// waiting for each one before submitting the next.
 // Prints one JSON line.  Build: see tools/serve_bench.sh.
 #include <algorithm>
 #include <atomic>
@@ -48,13 +50,16 @@ int main(int argc, char **argv) {
     std::fprintf(stderr, "batcher: %s\n", fdnn_last_error());
     return 1;
   }
+  const int inflight = std::max(1, std::getenv("INFLIGHT") ? std::atoi(std::getenv("INFLIGHT")) : 1);
   std::vector<std::vector<float>> xs(static_cast<size_t>(T)), outs(static_cast<size_t>(T));
+  std::vector<std::vector<std::vector<float>>> more(static_cast<size_t>(T));  // result blocks 1 .. inflight - 1 of a caller
   std::mt19937 rng(7);
   std::normal_distribution<float> nd(0.0f, 15.0f);
   for (int t = 0; t < T; ++t) {
     xs[size_t(t)].resize(size_t(F) * D);
     for (float &v : xs[size_t(t)]) v = nd(rng);
     outs[size_t(t)].assign(size_t(F) * O, 0.0f);  // resident, like a reused JVM float[]
+    if (srv) more[size_t(t)].assign(size_t(inflight - 1), std::vector<float>(size_t(F) * O, 0.0f));
   }
   // lazy modes: per thread, masks with 40 % of the nodes active in every frame and 3 % churn from frame to frame
   // (FuncTest.java:121-154's statistics), as bits
@@ -83,6 +88,19 @@ int main(int argc, char **argv) {
   std::atomic<int> failed{0};
   static thread_local volatile float sink = 0.0f;
   auto body = [&](int t, int utts) {
+    if (srv && inflight > 1) {  // a window of `inflight` tickets per caller
+      std::vector<uint64_t> tk(size_t(inflight), 0);
+      for (int u = 0; u < utts + inflight; ++u) {
+        const size_t slot = size_t(u % inflight);
+        if (u >= inflight && fdnn_server_wait(srv, tk[slot])) ++failed;
+        if (u >= utts) continue;
+        float *o = slot == 0 ? outs[size_t(t)].data() : more[size_t(t)][slot - 1].data();
+        const int rc = lazy ? fdnn_server_submit_lazy_bits(srv, xs[size_t(t)].data(), F, bits[size_t(t)].data(), o, &tk[slot])
+                            : fdnn_server_submit(srv, xs[size_t(t)].data(), F, nullptr, o, &tk[slot]);
+        if (rc) ++failed;
+      }
+      return;
+    }
     for (int u = 0; u < utts; ++u) {
       int rc;
       if (srv && lazy) {
