@@ -361,3 +361,45 @@ def test_one_call_lazy_through_the_model_batcher(mid_model_path):
     for k, g in enumerate(got):
         assert np.array_equal(g, want[k % 10]), k
     dnn.delete()
+
+
+def test_lazy_loop_on_the_full_net_with_large_coalesced_batches(net_model_path):
+    """BASELINE configs[1]-sized utterances (1000 frames) on the 432 -> 7x2048 -> 8000 net, eight callers, bit masks through
+    the scoring loop: the coalesced batches (up to 6400 frames) take the large-batch kernels -- int8-screened layer 0, the
+    masked output instance with the soft-max inside, the bits read as they are -- and come back compacted; every row equals
+    the same utterance through the one-call entry, sampled rows equal the oracle's LazyOutputActivations (dnn.cc:355-392)."""
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    O = dnn.outputDimension()
+    lens = [1000, 1000, 640, 1000, 100, 1000, 2700, 1000]
+    utts = [F.synth_features(n, 432, seed=900 + i) for i, n in enumerate(lens)]
+    masks = [F.generate_masks_fast(n, O, 0.40, 0.03, seed=60 + i) for i, n in enumerate(lens)]
+    bits = [F.pack_mask_bits(m) for m in masks]
+    alone = [dnn.calculateLazy(x, bits=b) for x, b in zip(utts, bits)]
+    orc = Oracle(net_model_path)
+    idx = np.array([0, 1, 499, 999])
+    assert np.abs(alone[0][idx] - orc.lazy(utts[0][idx], masks[0][idx])).max() <= TIGHT
+    srv = api.ScoringServer(dnn, max_frames=6400, depth=3, linger_us=300)
+    outs = [np.full((n, O), -5.0, dtype=np.float32) for n in lens]
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(3):
+                outs[i].fill(-5.0)
+                t, _ = srv.submitLazy(utts[i], bits[i], out=outs[i])
+                srv.wait(t)
+                assert np.array_equal(outs[i], alone[i]), i
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(lens))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    st = srv.stats()
+    assert st["coalesced_requests"] > 0 and st["frames"] == 3 * sum(lens)
+    assert dnn.fuseGiveups() == 0
+    srv.close()
+    dnn.delete()
