@@ -31,7 +31,9 @@ Rank 0 prints ONE JSON line (contract in the task statement) with
   lazy_40pct           BASELINE configs[3]: LazyContext contract, 40 % mask with 3 % churn, same batch
   small_batch          one 100-frame utterance / one 8-frame block per call, device resident: us per call, weight-stream
                        GB/s against the 8 TB/s HBM figure (the regime of the reference's own callers)
-  serving              16 caller threads x 100-frame utterances host-to-host: streams at real time per GPU
+  serving              16 caller threads x 100-frame utterances host-to-host: dense per call / through the scoring loop, the
+                       lazy contract per call and through the loop (fdnn_server_submit_lazy_bits), from Python threads and
+                       (native_harness) from tools/serve_bench.cpp
   cpu_baseline         the compiled reference itself (oracle/_ref; the oracle's SSE4.1 port as fallback) on this host's cores, N=1 only
 Setup (model load, 0.5 s of untimed passes that bring a cold device to its sustained clocks,
 reported as `setup.clock_ramp_steps`) comes before the W warm-up steps.
