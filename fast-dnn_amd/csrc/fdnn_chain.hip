@@ -55,7 +55,8 @@ namespace {
 // XCD this wave runs on: s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, 4 bits)
 __device__ __forceinline__ int xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7; }
 
-template <int NF, int WN, int BK, int STAGES, int WM>
+// NOFIX: no layer of the chain has saturating pairs -- the k-loop without the entry walk (fdnn_gemm.hip)
+template <int NF, int WN, int BK, int STAGES, int WM, bool NOFIX = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void qchain_kernel(QChainParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using Cfg = GemmCfg<NF, WN, BK, STAGES, WM>;
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qchain_kernel(QChainParams p)
       // pmaddubsw pair saturation (dnn.cc:337-340): the entry walk of fdnn_gemm.hip
       ent_c = (FixPtr)(uintptr_t)L->fix_ent;
       fix_node0 = m0 + 64 * wm;
-      if (ent_c) {
+      if (!NOFIX && ent_c) {
         const int32_t *fix_grp = L->fix_grp;
         const int grp = (m0 >> 6) + wm;
         fix_e = __builtin_amdgcn_readfirstlane(fix_grp[grp]);
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qchain_kernel(QChainParams p)
       if (nb >= STAGES) nb -= STAGES;
       const char *wt = smem + buf * Cfg::STAGE;
       const char *at = wt + Cfg::W_BYTES;
-      while (fix_k_next < (kt + 1) * BK) {  // rare: a risky pair lives in this k-step (screen, then the exact correction)
+      while (!NOFIX && fix_k_next < (kt + 1) * BK) {  // rare: a risky pair lives in this k-step (screen, then the exact correction)
         const int node = static_cast<int>(fix_raw >> 32) - fix_node0;         // 0..63
         const int kl = static_cast<int>(fix_raw & 0xffff) - kt * BK;          // even, 0..BK-2
         const int w0 = static_cast<int8_t>(fix_raw >> 16), w1 = static_cast<int8_t>(fix_raw >> 24);
@@ -557,6 +558,7 @@ void launch_chain_cfg(const QChainParams &p, hipStream_t s) {
   constexpr int kLds = Cfg::LDS + 64;
   static_assert(kLds <= 160 * 1024, "LDS");
   auto k = qchain_kernel<NF, WN, BK, STAGES, WM>;
+  auto k_nofix = qchain_kernel<NF, WN, BK, STAGES, WM, true>;
   static std::atomic<unsigned long long> attr_set{0};
   static std::atomic<int> cus[64];
   int dev = 0;
@@ -564,6 +566,7 @@ void launch_chain_cfg(const QChainParams &p, hipStream_t s) {
   const unsigned long long dev_bit = 1ull << (dev & 63);
   if (!(attr_set.load(std::memory_order_acquire) & dev_bit)) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_nofix), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     int n_cu = 256;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
     cus[dev & 63].store(n_cu, std::memory_order_relaxed);
@@ -572,7 +575,9 @@ void launch_chain_cfg(const QChainParams &p, hipStream_t s) {
   const int per_cu = (160 * 1024) / kLds >= 2 && Cfg::THREADS <= 256 ? 2 : 1;
   const long tiles = static_cast<long>(p.rows_pad / Cfg::G_BM) * (p.n_pad / Cfg::FT);
   const int grid = static_cast<int>(std::min<long>(tiles, static_cast<long>(cus[dev & 63].load(std::memory_order_relaxed)) * per_cu));
-  hipLaunchKernelGGL(k, dim3(grid), dim3(Cfg::THREADS), kLds, s, p);
+  bool any_fix = false;
+  for (int i = 0; i < p.n_layers; ++i) any_fix = any_fix || p.layer[i].fix_ent != nullptr;
+  hipLaunchKernelGGL(any_fix ? k : k_nofix, dim3(grid), dim3(Cfg::THREADS), kLds, s, p);
 }
 
 }  // namespace

@@ -74,8 +74,11 @@ namespace {
 // FUSED (with OUTPUT, PLAIN, FAST; 8-wave shapes): the soft-max scale inside this kernel -- every workgroup keeps its
 // exp(z) tile in the accumulator registers, the 256-node tiles of a frame tile exchange their row sums through memory,
 // and what leaves is probabilities: no exp(z) round trip through HBM, no normalize pass ("fused soft-max" below).
+// NOFIX (the large production shapes): a layer WITHOUT saturating pairs (fix_ent == null: trained, heavy-tailed nets) runs an
+// instance whose k-loop does not contain the entry walk at all -- the never-taken walk costs the loop 1.4 % (LABBOOK round 5:
+// 596.2 -> 587.8 us per 10 000-frame pass of the pair-free bench net).
 template <int NF, int WN, int BK, int STAGES, bool OUTPUT, bool TAP, bool FAST, bool PLAIN = false, bool MASKED = false, bool ANYW = false,
-          int WM = 4, bool FUSED = false>
+          int WM = 4, bool FUSED = false, bool NOFIX = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the host pass only needs the launch stub (buffer-resource builtins are device-only)
   using Cfg = GemmCfg<NF, WN, BK, STAGES, WM>;
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
   typedef const __attribute__((address_space(4))) uint64_t *FixPtr;
   const FixPtr ent_c = (FixPtr)(uintptr_t)p.fix_ent;
   uint64_t fix_raw = 0, fix_raw_nxt = 0;  // {u16 k, s8 w0, s8 w1, s32 node}
-  if (p.fix_ent) {
+  if (!NOFIX && p.fix_ent) {
     const int grp = (m0 >> 6) + wm;
     fix_e = __builtin_amdgcn_readfirstlane(p.fix_grp[grp]);
     fix_end = __builtin_amdgcn_readfirstlane(p.fix_grp[grp + 1]);
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
     const long long tf0 = __builtin_readcyclecounter();
     const int fe0 = fix_e;
 #endif
-    while (fix_k_next < (kt + 1) * BK) {  // rare: a risky pair lives in this k-step
+    while (!NOFIX && fix_k_next < (kt + 1) * BK) {  // rare: a risky pair lives in this k-step
       const int node = static_cast<int>(fix_raw >> 32) - (m0 + 64 * wm);  // 0..63
       const int kl = static_cast<int>(fix_raw & 0xffff) - kt * BK;          // even, 0..BK-2
       const int w0 = static_cast<int8_t>(fix_raw >> 16), w1 = static_cast<int8_t>(fix_raw >> 24);
@@ -1102,6 +1105,15 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
   auto k_fused_masked = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, kCanFuse, false, WM, kCanFuse>;
   auto k_fused_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, false, kCanFuse, WM, kCanFuse>;  // widths % 32 != 0
   auto k_fused_masked_anyw = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, kCanFuse, kCanFuse, WM, kCanFuse>;
+  // layers without saturating pairs, the 8-wave production shapes: no entry walk in the loop (the other shapes: the same kernels)
+#ifdef FDNN_NO_NOFIX  // (measurement builds: the instances with the walk for every layer)
+  constexpr bool kNoFix = false;
+#else
+  constexpr bool kNoFix = FAST && WM == 4 && WN == 2 && NF >= 4;
+#endif
+  auto k_prod_nofix = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, false, false, false, WM, false, kNoFix && !OUTPUT>;
+  auto k_fused_nofix = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, false, false, WM, kCanFuse, kNoFix && kCanFuse>;
+  auto k_fused_masked_nofix = qgemm_kernel<NF, WN, BK, STAGES, OUTPUT, false, FAST, kCanFuse, kCanFuse, false, WM, kCanFuse, kNoFix && kCanFuse>;
   // the attribute is per device: a process may hold models on several GPUs
   static std::atomic<unsigned long long> attr_set{0};
   int dev = 0;
@@ -1118,6 +1130,9 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_masked), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_anyw), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_masked_anyw), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_prod_nofix), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_nofix), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_masked_nofix), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS);
     attr_set.fetch_or(dev_bit, std::memory_order_release);
   }
   if (kCanFuse && p.fuse_s != nullptr) {
@@ -1125,6 +1140,8 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     // unscaled is scaled by its frame tile's last workgroup: one launch)
     if ((p.rows & 31) != 0)
       hipLaunchKernelGGL(p.mask ? k_fused_masked_anyw : k_fused_anyw, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+    else if (kNoFix && p.fix_ent == nullptr)
+      hipLaunchKernelGGL(p.mask ? k_fused_masked_nofix : k_fused_nofix, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
     else
       hipLaunchKernelGGL(p.mask ? k_fused_masked : k_fused, dim3(MT * NT), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   } else if (p.tap_acc)
@@ -1137,6 +1154,8 @@ void launch_cfg(const QGemmParams &p, hipStream_t s) {
     hipLaunchKernelGGL(k_masked, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else if (OUTPUT && p.mask != nullptr)  // 8001 nodes: 0.33 ms against 0.41 through the general epilogue
     hipLaunchKernelGGL(k_masked_anyw, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
+  else if (kNoFix && !OUTPUT && p.fix_ent == nullptr)
+    hipLaunchKernelGGL(k_prod_nofix, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
   else
     hipLaunchKernelGGL(k_prod, dim3(blocks), dim3(Cfg::THREADS), Cfg::LDS, s, p);
 }
