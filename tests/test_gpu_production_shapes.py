@@ -713,3 +713,47 @@ def test_fused_softmax_with_arbitrary_output_widths(tmp_models, out_dim, n):
     assert np.abs(lgot - lwant).max() <= TIGHT
     assert dnn.fuseGiveups() == 0
     dnn.delete()
+
+
+@pytest.mark.parametrize("n", [10000, 12000])
+def test_layers_without_saturating_pairs_take_the_walk_free_instances(tmp_models, n):
+    """A layer whose list of saturating pairs is empty (trained, heavy-tailed nets) runs k-loops without the entry walk
+    (qgemm_kernel / qchain_kernel NOFIX: hidden layers per launch at 10 000 frames, chained at 12 000; the fused dense and
+    masked output instances).  Two nets of production width: no layer with pairs, and pairs in the third layer and the
+    output layer only (so that the chained kernel keeps its walk while the per-layer launches mix both kinds).  Last hidden
+    layer bit for bit and probabilities (dense and 40 % masks) against the oracle on sampled frames; both hidden-layer
+    forms equal."""
+    topo = [432, 1024, 1024, 1024, 1024, 2048]
+    clean = F.synth_net(topo, seed=31, mode="nosat")
+    mixed = F.synth_net(topo, seed=31, mode="nosat")
+    gauss = F.synth_net(topo, seed=31, mode="gauss")
+    for li in (2, 4):
+        mixed.layers[li] = gauss.layers[li]
+    x = F.synth_features(n, 432, seed=19)
+    masks = F.generate_masks_fast(n, topo[-1], 0.40, 0.03, seed=23)
+    idx = np.array(sorted(set(np.linspace(0, n - 1, 24).astype(int)) | {319, 320, n - 1}))
+    for name, net in (("clean", clean), ("mixed", mixed)):
+        p = os.path.join(tmp_models, f"nofix_{name}.bin")
+        F.write_model_bin(p, net)
+        pairs = [api.HostModel(p).risky_pairs(j) for j in range(1, len(topo) - 1)]
+        assert (sum(pairs) == 0) == (name == "clean"), pairs
+        if name == "mixed":
+            assert pairs[1] > 0 and pairs[0] == 0
+        dnn = api.QuantizedDnn.loadFromFile(p)
+        orc = Oracle(p)
+        want, taps = orc.calculate(x[idx], taps=True)
+        hid = {}
+        for mode in (0, 1):
+            api.set_chain(mode, 1)
+            ctx = dnn.getNewLazyContext(n)
+            ctx.calculateUntilOutput(x)
+            hid[mode] = ctx.hiddenActivations()[idx].copy()
+            lazy = ctx.calculateForOutputNodesBatch(masks)[idx].copy() if mode == 0 else None
+            ctx.delete()
+            if lazy is not None:
+                assert np.abs(lazy - orc.lazy(x[idx], masks[idx])).max() <= TIGHT, name
+        api.set_chain(-1)
+        assert np.array_equal(hid[0], taps["u8_acts"][-1]) and np.array_equal(hid[1], hid[0]), name
+        got = dnn.calculate(x)[idx]
+        assert np.abs(got - want).max() <= TIGHT, name
+        dnn.delete()
