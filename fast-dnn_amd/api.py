@@ -60,6 +60,7 @@ SIGNATURES = {
     "fdnn_model_set_l0_fma": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_set_l0_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_set_chain": (C.c_int, [C.c_int, C.c_int]),
+    "fdnn_debug_set_pp": (C.c_int, [C.c_int, C.c_int]),
     "fdnn_device_shared": (C.c_int, [C.c_int]),
     "fdnn_debug_set_fuse": (C.c_int, [C.c_int]),
     "fdnn_debug_set_l0_list_cap": (C.c_int, [C.c_void_p, C.c_int]),
@@ -214,6 +215,12 @@ def set_chain(mode: int, min_frames: int = 0) -> None:
     """How the int8 hidden layers run (process-wide; results are bit-identical): 1 = one persistent launch for batches of
     at least min_frames frames, 0 = one launch per layer, -1 = the default."""
     _check(lib().fdnn_debug_set_chain(int(mode), int(min_frames)))
+
+
+def set_pp(mode: int, min_frames: int = 0) -> None:
+    """How a large batch's int8 hidden layers run when launched layer by layer (process-wide; results are bit-identical):
+    1 = the role-split kernel (fdnn_pp.hip) for batches of at least min_frames frames, 0 = the in-phase tiles, -1 = default."""
+    _check(lib().fdnn_debug_set_pp(int(mode), int(min_frames)))
 
 
 class LazyContext:

@@ -146,6 +146,14 @@ bool qgemm_fused_ok(const QGemmParams &p);
 void launch_qgemm_hidden(const QGemmParams &p, hipStream_t s);
 void launch_qgemm_output(const QGemmParams &p, hipStream_t s);
 
+// An int8 hidden layer of a large batch with the two waves of every SIMD in different roles (fdnn_pp.hip): one computes
+// (fragment reads + MFMAs only) while its partner stages that tile's operands and runs the epilogue of the tile it computed
+// before.  256-node x 320-frame tiles (n_pad a multiple of qpp_frame_tile()), K = 2048, validated 3-operation division.
+bool qpp_ok(int rows_pad, int K, int n, bool fastdiv);
+void qpp_set_mode(int mode, int min_frames);  // fdnn_debug_set_pp
+int qpp_frame_tile();
+void launch_qpp_hidden(const QGemmParams &p, hipStream_t s);
+
 // The int8 HIDDEN layers of a pass in one persistent launch (fdnn_chain.hip): tasks (layer, frame tile, node tile) drawn
 // from per-XCD queues, a task waits only for its own frame tile's node tiles of the layer before.  All hidden layers of
 // a net have the same shape (README.md:10), so one set of sizes serves every layer.

@@ -449,9 +449,19 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
     g.act_out = c->d_act[cur ^ 1];
     g.act_ld = c->act_ld;
     g.tap_acc = (taps && taps->acc_hid) ? taps->acc_hid + size_t(qi) * c->n * h.hidden : nullptr;
+    // Large batches of the production shape: the role-split kernel (fdnn_pp.hip) -- one wave of each SIMD in the k-loop,
+    // its partner staging that tile's operands and running the epilogue of the tile before.  Identical bytes.
+    static const int pp_only = [] { const char *e = std::getenv("FDNN_PP_ONLY"); return e ? std::atoi(e) : -1; }();
+    const bool pp = !g.tap_acc && fdnn::qpp_ok(g.rows_pad, g.K, c->n, g.fastdiv != 0) && (pp_only < 0 || pp_only == qi);
+    if (pp) {
+      g.small = 0;
+      g.frame_tile = fdnn::qpp_frame_tile();
+      g.n_pad = round_up(c->n, g.frame_tile);
+    }
     {
       ProfScope ps(m, s, FDNN_PROF_HIDDEN);
-      fdnn::launch_qgemm_hidden(g, s);
+      if (pp) fdnn::launch_qpp_hidden(g, s);
+      else fdnn::launch_qgemm_hidden(g, s);
     }
     cur ^= 1;
     if (taps && taps->u8_acts) snapshot_acts(c, cur, taps->u8_acts + size_t(qi + 1) * c->n * h.hidden, s);
@@ -1087,6 +1097,12 @@ int fdnn_debug_set_l0_list_cap(fdnn_model *m, int cap) {
   for (fdnn_ctx *c : m->pool) destroy_ctx(c);  // pooled contexts carry the old capacity
   m->pool.clear();
   m->l0_list_cap = cap;
+  return FDNN_OK;
+}
+
+int fdnn_debug_set_pp(int mode, int min_frames) {
+  if (mode < -1 || mode > 1) return fail(FDNN_E_ARG, "pp mode must be -1, 0 or 1");
+  fdnn::qpp_set_mode(mode, min_frames);
   return FDNN_OK;
 }
 

@@ -300,6 +300,13 @@ FDNN_API int fdnn_debug_set_l0_list_cap(fdnn_model *m, int cap);
  * CalculateUntilLastHiddenLayer's layer loop, src/cpp/dnn.cc:413-423, is what is being computed. */
 FDNN_API int fdnn_debug_set_chain(int mode, int min_frames);
 
+/* How a large batch's int8 hidden layers run when they are launched layer by layer: 1 = the role-split kernel (fdnn_pp.hip:
+ * one wave of each SIMD in the k-loop, its partner staging that tile's operands and running the previous tile's epilogue)
+ * for batches of at least min_frames frames (<= 0: the default threshold), 0 = fdnn_gemm.hip's in-phase tiles, -1 = the
+ * default (FDNN_PP / FDNN_PP_MIN in the environment, else on from 8 193 frames).  Process-wide; identical bytes either way.
+ * QuantizedLayerActivations + AddBias + QuantizedSigmoid, src/cpp/dnn.cc:250-349, is what is being computed. */
+FDNN_API int fdnn_debug_set_pp(int mode, int min_frames);
+
 /* Measurement builds of the chained hidden-layer kernel (-DFDNN_CHAIN_CLK=1; the shipped library records nothing): with
  * out == NULL, give the context a buffer for the phase clocks of cap_tasks tasks; with out != NULL copy the records of the
  * launches since ([0] = tasks recorded, then from [8] ten words per task: block / task id, XCD / layer / frame tile, the

@@ -186,6 +186,69 @@ class Oracle:
             raise RuntimeError(f"oracle rc={rc}")
         return act
 
+    # ---- the same calls from several threads (ctypes drops the GIL; the model is read-only): every ROW of a
+    # production-size batch against the restatement in about a second per 10 000 frames on 16 cores
+    @staticmethod
+    def _chunks(n: int, threads: int):
+        threads = max(1, min(threads, n))
+        step = -(-n // threads)
+        return [(lo, min(n, lo + step)) for lo in range(0, n, step)]
+
+    @staticmethod
+    def default_threads() -> int:
+        try:
+            return max(1, min(32, len(os.sched_getaffinity(0))))
+        except AttributeError:
+            return max(1, min(32, os.cpu_count() or 1))
+
+    def hidden_acts_mt(self, x, threads: Optional[int] = None) -> np.ndarray:
+        """hidden_acts over frame ranges in parallel (frames are independent: dnn.cc:402-424 has no cross-frame state)."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        x = _f32(x)
+        n = x.shape[0]
+        act = np.zeros((n, self.hidden), dtype=np.uint8)
+        L = self.lib()
+
+        def run(r):
+            lo, hi = r
+            rc = L.orc_hidden(self.h, _ptr(x[lo:hi], C.c_float), hi - lo, 8, 1, _ptr(act[lo:hi], C.c_uint8), None)
+            if rc:
+                raise RuntimeError(f"oracle rc={rc}")
+
+        ch = self._chunks(n, threads or self.default_threads())
+        with ThreadPoolExecutor(len(ch)) as ex:
+            list(ex.map(run, ch))
+        return act
+
+    def output_mt(self, act, masks=None, want_acc: bool = False, threads: Optional[int] = None):
+        """CalculateOutput (dnn.cc:428-454) -- or, with masks, LazyOutputActivations per frame (dnn.cc:355-392) -- over the
+        given last-hidden-layer activations, frame ranges in parallel.  Returns probs, or (probs, acc_out int32)."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        act = np.ascontiguousarray(act, dtype=np.uint8)
+        n = act.shape[0]
+        out = np.zeros((n, self.out_dim), dtype=np.float32)
+        acc = np.zeros((n, self.out_dim), dtype=np.int32) if want_acc else None
+        if masks is not None:
+            masks = np.ascontiguousarray(masks, dtype=np.int8)
+        L = self.lib()
+
+        def run(r):
+            lo, hi = r
+            if masks is not None:
+                rc = L.orc_lazy_batch(self.h, _ptr(act[lo:hi], C.c_uint8), hi - lo, _ptr(masks[lo:hi], C.c_int8), 1, _ptr(out[lo:hi], C.c_float))
+            else:
+                t = _Taps(None, None, _ptr(acc[lo:hi], C.c_int32) if want_acc else None, None, None, 0)
+                rc = L.orc_output(self.h, _ptr(act[lo:hi], C.c_uint8), hi - lo, 8, 1, _ptr(out[lo:hi], C.c_float), C.byref(t) if want_acc else None)
+            if rc:
+                raise RuntimeError(f"oracle rc={rc}")
+
+        ch = self._chunks(n, threads or self.default_threads())
+        with ThreadPoolExecutor(len(ch)) as ex:
+            list(ex.map(run, ch))
+        return (out, acc) if want_acc else out
+
     def lazy(self, x, masks, batch: int = 8, sse: bool = True) -> np.ndarray:
         """LazyContext: calculateUntilOutput(x) then calculateForOutputNodes(mask) per frame."""
         act = self.hidden_acts(x, batch, sse)
