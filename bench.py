@@ -51,6 +51,7 @@ import numpy as np  # noqa: E402
 
 FRAMES_PER_GPU = 10000
 INT8_PEAK_TOPS = 5000.0  # dense int8 MFMA, 2x the 2.5 PF bf16 dense peak (MI355X_MICROARCH.md)
+INT8_MEASURED_TOPS = 3944.0  # what a bare int8 MFMA microbenchmark reaches (MI355X_MICROARCH.md, matrix-core table)
 FP32_NOFMA_TFLOPS = 78.65  # fp32 vector peak 157.3 counts an fma as two; multiply and add rounded separately -> half
 HBM_PEAK_GBS = 8000.0
 WEIGHT_BYTES_PER_PASS = 41_549_824 + 3_538_944 + 89_344 + 3_456  # int8 layers + fp32 layer 0 + biases + shift/scale = 45.2 MB
@@ -262,6 +263,69 @@ def rank_report(dist, world: int, rank: int, digest: str, own_frames_per_s: floa
             "devices": [p[3] for p in parts], "distinct_devices": len(set(keys)), "peer_access_from_rank0": peers}
 
 
+def numa_cpus_of_device(local: int):
+    """CPUs next to GPU `local` (sysfs local_cpulist of its PCI function), or None: the host-fed callers of a rank are kept on
+    the socket its GPU hangs off (per-rank pinned buffers + NUMA-local callers: SURVEY 8(e))."""
+    try:
+        import torch
+
+        bdf = torch.cuda.get_device_properties(local).pci_bus_id if hasattr(torch.cuda.get_device_properties(local), "pci_bus_id") else None
+        if not bdf:
+            return None
+        txt = open(f"/sys/bus/pci/devices/{str(bdf).lower()}/local_cpulist").read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = os.sched_getaffinity(0)
+        return sorted(cpus & allowed) or None
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def host_fed_leg(make_caller, threads: int, per: int, frames_per_utt: int, fence, dist, world: int, red_dev, cpus=None) -> dict:
+    """N > 1's host-fed shape (the reference's concurrency model, MultiThreadedStressTest.java:48-69: independent caller
+    threads over one immutable model, the result rows copied out per call, jni_dnn.cc:54-57): on EVERY rank `threads` caller
+    threads score `per` utterances of `frames_per_utt` frames each, host frames in, host soft-max rows out; one untimed
+    round, then one round bracketed by fence() on both sides, max over ranks.  make_caller(t) -> the thread's body."""
+    import threading
+
+    def one_round():
+        th = [threading.Thread(target=make_caller(t)) for t in range(threads)]
+        for h in th:
+            h.start()
+        for h in th:
+            h.join()
+
+    old_aff = None
+    if cpus:
+        try:
+            old_aff = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, cpus)  # (threads started from here inherit it)
+        except Exception:  # noqa: BLE001
+            old_aff = None
+    one_round()
+    fence()
+    t0 = time.perf_counter()
+    one_round()
+    fence()
+    own = time.perf_counter() - t0
+    if old_aff is not None:
+        os.sched_setaffinity(0, old_aff)
+    el = max_over_ranks(dist, world, own, red_dev)
+    own_rate = threads * per / own
+    rates = [own_rate]
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, own_rate)
+        rates = parts
+    return {"utterances_per_s_whole_node": round(world * threads * per / el, 1),
+            "frames_per_s_whole_node": round(world * threads * per * frames_per_utt / el, 1),
+            "per_rank_utterances_per_s": [round(r, 1) for r in rates],
+            "caller_threads_per_rank": threads, "utterances_per_thread": per, "frames_per_utterance": frames_per_utt,
+            "numa_local_cpus": None if not cpus else len(cpus)}
+
+
 def stub_main(args, rank: int, world: int) -> None:
     """--stub-scorer: the N-rank protocol of main() without a GPU.  gloo, host tensors; rank 0 quantizes and packs the tiny
     model with the library's host half (no device needed), the blob is broadcast and validated on every rank, the timed
@@ -299,6 +363,24 @@ def stub_main(args, rank: int, world: int) -> None:
     own = timed_steps(submit, lambda: None, fence, args.warmup, args.steps)
     elapsed = max_over_ranks(dist, world, own, dev)
     rep = rank_report(dist, world, rank, digest, n * args.steps / own, "cpu (stub)", device_key="cpu", shared=True)
+    # the two host-fed legs of the N-rank line, with the stub scorer: per-rank caller threads, and one process over N "devices"
+    bufs = [np.empty((100, O), dtype=np.float32) for _ in range(4)]
+
+    def make_caller(t):
+        def body():
+            for _ in range(10):
+                bufs[t].fill(1.0 / O)
+        return body
+
+    host_fed = host_fed_leg(make_caller, 4, 10, 100, fence, dist, world, dev)
+    one_process = None
+    if rank == 0:
+        t0 = time.perf_counter()
+        for _ in range(3):
+            for _d in range(world):
+                out.fill(1.0 / O)
+        one_process = {"devices": world, "frames_per_s_whole_node": round(3 * world * n / (time.perf_counter() - t0), 1), "stub": True}
+    fence()
     if rank == 0:
         print(json.dumps({
             "metric": "acoustic frames/sec (whole node), 7x2048->8000 nnet", "value": round(world * n * args.steps / elapsed, 1),
@@ -307,7 +389,7 @@ def stub_main(args, rank: int, world: int) -> None:
             "dtype": "none (stub scorer)", "data": "synthetic",
             "config": {"workload": "STUB: launch / rendezvous / broadcast / timing protocol only, no scorer, no GPU", "frames_per_gpu": n,
                        "global_frames": world * n, "parallelism": f"frame-sharded x{world}, replicated weights"},
-            "multi_gpu": rep, "stub": True}), flush=True)
+            "multi_gpu": rep, "host_fed": host_fed, "one_process_group": one_process, "stub": True}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -338,8 +420,10 @@ def main() -> None:
     ap.add_argument("--in-flight", type=int, default=2, help="steps in flight in the scoring loop (1 = no overlap between steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-lazy", action="store_true", help="skip the configs[3] leg")
+    ap.add_argument("--no-nosat", action="store_true", help="skip the pair-free-net extra")
     ap.add_argument("--no-small", action="store_true", help="skip the small-batch (100- and 8-frame call) leg")
     ap.add_argument("--no-serving", action="store_true", help="skip the 100-frame-utterance serving leg")
+    ap.add_argument("--host-fed", action="store_true", help="N = 1: also run the N > 1 host-fed legs (per-rank caller threads, one-process group)")
     ap.add_argument("--clock-ramp-s", type=float, default=0.5, help="seconds of untimed load before the W warm-up steps (setup)")
     ap.add_argument("--single-stream-only", action="store_true",
                     help="profiling runs (tools/profile_round.sh): only the back-to-back single-stream steps, so that rocprofv3's "
@@ -467,6 +551,8 @@ def main() -> None:
     multi = rank_report(dist, world, rank, blob_digest, n * args.steps / own_elapsed,
                         f"{torch.cuda.get_device_name(local)} #{local}", device_key=dev_key, shared=bool(args.share_device), peers=peers)
     multi["shared_device"] = bool(args.share_device)
+    if world > 1 and not args.share_device:
+        assert multi["rccl_ranks"] == world, f"RCCL process group has {multi['rccl_ranks']} ranks, {world} expected"
     assert multi["blob_sha256_all_equal"], "ranks hold different weight blobs"
 
     # sanity on the last outputs: soft-max rows sum to one, every in-flight buffer holds the same result
@@ -502,6 +588,54 @@ def main() -> None:
                    "frames_per_gpu": n4}
         del x4, o4
 
+    # ---- N > 1: the HOST-FED shapes, beside the device-resident figure (which scales by construction).  SURVEY 8(e): what
+    # threatens ">= 6x at 8 GPUs" is feeding -- every GPU's 32 KB per frame back to one host's memory.  (a) per rank: caller
+    # threads over 100-frame utterances through the rank's scoring loop (fdnn_server_submit + wait), host rows in and out, the
+    # callers kept on the GPU's socket; (b) ONE process over all N devices (fdnn_group_calculate, FDNN_DEVICES): rank 0 only,
+    # the other ranks idle at a barrier.  Neither is `value`.
+    host_fed, one_process = None, None
+    if (world > 1 or args.host_fed) and not args.no_serving:
+        T_hf, per_hf, uf_hf = 8, 40, 100
+        utt_hf = F.synth_features(uf_hf, 432, seed=5 + rank)
+        bufs_hf = [np.zeros((uf_hf, O), dtype=np.float32) for _ in range(T_hf)]
+        hsrv = api.ScoringServer(dnn, 6400, 3, 100)
+
+        def make_caller(t):
+            def body():
+                for _ in range(per_hf):
+                    tk, _o = hsrv.submit(utt_hf, out=bufs_hf[t])
+                    hsrv.wait(tk)
+            return body
+
+        host_fed = host_fed_leg(make_caller, T_hf, per_hf, uf_hf, fence, dist, world, red_dev, cpus=numa_cpus_of_device(local))
+        hsrv.close()
+        assert abs(float(bufs_hf[0].sum(1).mean()) - 1.0) < 1e-3
+        host_fed["device_to_host_GB_per_s_whole_node"] = round(host_fed["frames_per_s_whole_node"] * O * 4 / 1e9, 1)
+        host_fed["note"] = ("per rank: fdnn_server_submit + wait from caller threads pinned to the GPU's socket, 100-frame utterances, host frames in / "
+                            "host soft-max rows out (32 KB per frame); whole node = all ranks' utterances over the slowest rank's time")
+        if not args.share_device:
+            n_dev = torch.cuda.device_count() if world > 1 else 1
+            if rank == 0:
+                try:
+                    grp = api.DeviceGroup(model_path, list(range(min(n_dev, world))))
+                    ng = grp.size() * 2000  # 2 000 frames per device per call: 64 MB of rows back per device
+                    xg = F.synth_features(ng, 432, seed=77)
+                    grp.calculate(xg[: grp.size() * 200])
+                    tg = time.perf_counter()
+                    reps_g = 3
+                    for _ in range(reps_g):
+                        pg = grp.calculate(xg)
+                    eg = time.perf_counter() - tg
+                    assert abs(float(pg[:8].sum(1).mean()) - 1.0) < 1e-3
+                    one_process = {"devices": grp.size(), "frames_per_call": ng, "frames_per_s_whole_node": round(reps_g * ng / eg, 1),
+                                   "weight_transport": grp.weightTransport(),
+                                   "note": "api.DeviceGroup.calculate = fdnn_group_calculate: one process, one worker thread per device, "
+                                           "contiguous frame shards, host frames in / host rows out"}
+                    grp.delete()
+                except Exception as e_:  # noqa: BLE001
+                    one_process = {"error": str(e_)[:300]}
+            fence()
+
     # ---- per-kernel HIP events over the same K steps (single stream; rank 0 reports)
     dnn.profileBegin()
     for _ in range(args.steps):
@@ -522,6 +656,30 @@ def main() -> None:
         torch.cuda.synchronize()
         alt = n * args.steps / (time.perf_counter() - t2)
         dnn.setInputLayerFma(args.l0_fma)
+
+    # ---- the same topology WITHOUT saturating weight pairs (a trained, heavy-tailed net has few: SURVEY 7 hard part 2): what
+    # the Gaussian bench net's pair screens cost shows as the difference to the headline's single-stream figure
+    nosat = None
+    if world == 1 and args.mode == "gauss" and not args.no_nosat:
+        try:
+            np_path = os.path.join(tmp, "fdnn_net_seed1_nosat.bin")
+            F.ensure_model_file(np_path, F.NET_TOPOLOGY, seed=1, mode="nosat")
+            dn = api.QuantizedDnn.loadFromFile(np_path)
+            for _ in range(max(5, args.warmup)):
+                dn.calculate_device(x.data_ptr(), n, outs[0].data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            tn = time.perf_counter()
+            for _ in range(args.steps):
+                dn.calculate_device(x.data_ptr(), n, outs[0].data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            en = time.perf_counter() - tn
+            nosat = {"frames_per_s_single_stream": round(n * args.steps / en, 1), "ms_per_step": round(en / args.steps * 1e3, 4),
+                     "vs_headline_net_single_stream": round((single_elapsed / args.steps) / (en / args.steps), 4),
+                     "note": "same 432 -> 7x2048 -> 8000 topology and seed, weights quantised so that no adjacent pair can leave int16 "
+                             "(|w_q| <= 64): the layers run the instances without the pair-saturation walk"}
+            dn.delete()
+        except Exception as e_:  # noqa: BLE001
+            nosat = {"error": str(e_)[:200]}
 
     # ---- BASELINE configs[3]: the lazy contract, 40 % of the output nodes active, 3 % churn per frame
     lazy = None
@@ -608,6 +766,35 @@ def main() -> None:
                                    "weight_stream_GB_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4),
                                    "x_realtime_one_stream": round(sn / us * 1e6 / 100.0, 1)})
         assert abs(float(outs[0][:8].sum(1).mean().item()) - 1.0) < 1e-3
+        # An honest bound for this regime (round 5 reported "0.09 of the HBM peak": the weights do not come from HBM -- 45 MB sit
+        # in the 256 MB Infinity Cache between calls -- and one workgroup's operand stream, not the chip's, is what a launch waits
+        # for).  Per launch: the bytes ONE workgroup pulls through its CU's L2 -> LDS path at the 42 B/clk/CU that path delivers
+        # (tools/ubench_dma_waves.hip), plus the stream's kernel boundary (1.45 us between trivial dependent kernels,
+        # MI355X_MICROARCH.md price list).  100 frames: hidden layer = 64 KB of weights + 64 KB of activation rows per 32 x 32
+        # tile; output layer = two 64-node tiles per CU (128 KB weights + 64 KB rows each); layer 0 = 110 KB + 27 KB per tile.
+        clk = 2.1e9
+        per_cu = 42.0 * clk
+        stream_us = (6 * 131072 + 2 * 196608 + 141312) / per_cu * 1e6
+        chain_us = 9 * 1.45
+        c100 = small["calls"][0]["us_per_call"]
+        rs = {"call": "100 frames, device resident", "measured_us": c100,
+              "bound": "per-workgroup operand stream through one CU's L2->LDS path (42 B/clk/CU) + the launch chain (9 dependent launches)",
+              "operand_stream_us": round(stream_us, 2), "launch_chain_us": round(chain_us, 2), "floor_us": round(stream_us + chain_us, 2),
+              "frac": round((stream_us + chain_us) / c100, 4),
+              "note": "a model, not a counter: bytes per workgroup from fdnn_small.hip's tile shapes; what the rest is -- first-stage "
+                      "latency behind every boundary, the in-workgroup split-K reduction, the scale pass as a ninth launch -- is in "
+                      "profiles/r06_small_100_kernel_stats.csv / r06_small_100_pmc.json (rocprofv3, replayed below when committed)"}
+        for nn_ in (100, 1000):
+            try:
+                import csv
+
+                rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"r06_small_{nn_}_kernel_stats.csv"))))
+                ks = {r_["Name"].split("fdnn::")[-1].split("(")[0][:60]: round(float(r_["AverageNs"]) / 1e3, 2) for r_ in rows if "fdnn" in r_["Name"] and int(r_["Calls"]) >= 100}
+                rs[f"kernel_avg_us_{nn_}_frames_replayed"] = ks
+                rs["replayed_from"] = "profiles/r06_small_*_kernel_stats.csv"
+            except Exception:  # noqa: BLE001
+                pass
+        small["roofline_small"] = rs
         small["note"] = ("fdnn_calculate_device, device-resident frames in and soft-max rows out, nine launches per call (layer 0, six "
                          "hidden layers, output layer, soft-max scale) on the small-batch kernels (fdnn_small.hip, l0_small_kernel); "
                          "round 2 took 119 / 115 us for these two calls")
@@ -765,7 +952,7 @@ def main() -> None:
         # WRITE_SIZE in separate runs, FETCH_SIZE doubled as the gfx950 guide prescribes); bench.py
         # itself cannot run under rocprof.  Newest round first.
         pmc, pmc_file = {}, None
-        for cand in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+        for cand in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 pmc_file = cand
@@ -796,9 +983,15 @@ def main() -> None:
             per_launch_ms = pr["ms"] / pr["launches"]
             per_step_ms = pr["ms"] / steps
             achieved = work_per_launch / (per_launch_ms * 1e-3) / scale
+            traffic = traffic_of(pmc_prefix)
             kinds.append({
                 "kernel": kernel, "bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
-                "frac": round(achieved / peak, 4), "traffic": traffic_of(pmc_prefix),
+                "frac": round(achieved / peak, 4),
+                # against what a bare MFMA microbenchmark reaches on this chip (MI355X_MICROARCH.md: >= 3 944 TOP/s int8)
+                "frac_of_measured_ceiling": round(achieved / INT8_MEASURED_TOPS, 4) if unit == "TOP/s" else None,
+                "traffic": traffic,
+                # NOT measured in this run: the HBM-side bytes per launch of the committed rocprofv3 --pmc passes
+                "traffic_replayed_from": f"profiles/{pmc_file}" if traffic is not None else None,
                 "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(per_launch_ms, 4),
                 "launches_per_step": pr["launches"] // steps, "ms_per_step": round(per_step_ms, 4),
                 "share_of_single_stream_step": round(per_step_ms / (single_elapsed / steps * 1e3), 4),
@@ -838,10 +1031,13 @@ def main() -> None:
         dominant = max(kinds, key=lambda k: k["ms_per_step"])
         gemm = next(k for k in kinds if k["kernel"].startswith("qgemm_kernel<hidden>") or k["kernel"].startswith("qchain_kernel"))
         rocprof = None
-        try:  # the same fractions from the committed rocprofv3 averages (tools/profile_round.sh)
-            rocprof = json.load(open(os.path.join(ROOT, "profiles", "r05_roofline.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_roofline.json")) else "r04_roofline.json")))
-        except Exception:
-            pass
+        for cand in ("r06_roofline.json", "r05_roofline.json", "r04_roofline.json"):  # the same fractions from the committed rocprofv3 averages (tools/profile_round.sh)
+            try:
+                rocprof = dict(json.load(open(os.path.join(ROOT, "profiles", cand))), replayed_from=f"profiles/{cand}",
+                               replay_note="committed rocprofv3 averages of an earlier run of this command, NOT quantities of this run")
+                break
+            except Exception:  # noqa: BLE001
+                continue
         value = world * n * steps / elapsed
         res = {
             "metric": "acoustic frames/sec (whole node), 7x2048->8000 nnet",
@@ -850,6 +1046,8 @@ def main() -> None:
             "n_gpus": world,
             "multi_gpu": multi,
             "config4_125k_per_gpu": config4,
+            "host_fed": host_fed,
+            "one_process_group": one_process,
             "steps": steps,
             "warmup": args.warmup,
             "ms_per_step": round(step_ms, 4),
@@ -872,7 +1070,7 @@ def main() -> None:
             "single_stream": {"frames_per_s": round(world * n * steps / single_elapsed, 1), "ms_per_step": round(single_elapsed / steps * 1e3, 4),
                               "note": "the same K steps as back-to-back fdnn_calculate_device calls on one stream (no overlap between steps)"},
             "roofline": dict(dominant, note="largest share of the step; times from HIP events on the launch stream, which add ~4 us per "
-                                            "bracketed launch -- profiles/r05_roofline.json holds the rocprofv3 averages"),
+                                            "bracketed launch; `traffic` is replayed from the committed PMC passes (traffic_replayed_from), frac / avg_launch_ms are live"),
             "roofline_int8_gemm": gemm,
             "roofline_kernels": kinds,
             "end_to_end": {"bound": "mfma", "achieved": round(value / world, 1), "peak": round(ROOFLINE_FRAMES_PER_S, 1), "unit": "frames/s per GPU",
@@ -888,6 +1086,7 @@ def main() -> None:
             "other_layer0_flavour": None if alt is None else {
                 "layer0_numerics": "unfused (canonical)" if args.l0_fma else "fused (reference built -march=native), fp32 MFMA",
                 "frames_per_s_single_stream": round(alt, 1)},
+            "nosat_pair_free_net": nosat,
             "lazy_40pct": lazy,
             "config1_1000": config1,
             "small_batch": small,

@@ -60,6 +60,7 @@ SIGNATURES = {
     "fdnn_model_set_l0_fma": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_set_l0_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_debug_set_chain": (C.c_int, [C.c_int, C.c_int]),
+    "fdnn_model_chain_faults": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "fdnn_debug_set_pp": (C.c_int, [C.c_int, C.c_int]),
     "fdnn_device_shared": (C.c_int, [C.c_int]),
     "fdnn_debug_set_fuse": (C.c_int, [C.c_int]),
@@ -572,6 +573,12 @@ class QuantizedDnn:
         """Tiles of the fused soft-max that had to be finished by the clean-up kernel since load (fdnn_model_fuse_giveups)."""
         v = C.c_ulonglong(0)
         _check(lib().fdnn_model_fuse_giveups(self.nativeDnnHandle, C.byref(v)))
+        return int(v.value)
+
+    def chainFaults(self) -> int:
+        """Waits of the chained hidden-layer kernel that ran into their bound since load (0 in a healthy setup)."""
+        v = C.c_ulonglong()
+        _check(lib().fdnn_model_chain_faults(self.nativeDnnHandle, C.byref(v)))
         return int(v.value)
 
     def deviceCounters(self, n: int = 32):

@@ -267,6 +267,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qchain_kernel(QChainParams p)
             __builtin_amdgcn_s_sleep(FDNN_CHAIN_SLEEP);
             if (++spins > (1 << 22)) {  // seconds (a legitimate wait is microseconds): counters left dirty by a killed launch
               if (kp->faults) atomicAdd(kp->faults, 1ull);
+              if (kp->fault_flag) __hip_atomic_store(kp->fault_flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // host-visible: the pass is wrong and says so
               break;
             }
           }
@@ -610,7 +611,12 @@ bool qchain_ok(int rows_pad, int K, int n, int n_layers) {
   if (forced == 1) return true;  // (tests / measurements: wherever the shape allows)
   // ... and only where a launch per layer would run a partly filled round: at whole rounds of 320-frame tiles (10 000 /
   // 10 240 / 20 480 frames on a 2048-wide net) the two forms are within +-2 % of each other, the sign depending on the box.
-  const long tiles = static_cast<long>(rows_pad / 256) * ((n + 319) / 320), cus = 256;
+  static const long cus = [] {  // (advisor, round 5: not a hard-coded 256)
+    int dev = 0, n_cu = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    return static_cast<long>(n_cu);
+  }();
+  const long tiles = static_cast<long>(rows_pad / 256) * ((n + 319) / 320);
   const long idle = (tiles + cus - 1) / cus * cus - tiles;
   return idle >= 24;
 }

@@ -49,6 +49,9 @@
 #ifndef FDNN_GEMM_DEBUG
 #define FDNN_GEMM_DEBUG 0
 #endif
+#ifndef FDNN_GEMM_PIN
+#define FDNN_GEMM_PIN 0  // 1: fragment reads pinned one behind each MFMA of the sub-step before (sched_group_barrier)
+#endif
 #ifndef FDNN_FUSE_PARTS
 #define FDNN_FUSE_PARTS 2  // parts of the fused soft-max's row-sum exchange (one per 32-frame block at most)
 #endif
@@ -445,6 +448,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
           acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[kk & 1][mi], b[kk & 1][ni], acc[mi][ni], 0, 0, 0);
+#if FDNN_GEMM_PIN
+      // Round 6 (tools/ubench_role.hip, tools/ubench_tile.hip): one of the next sub-step's fragment reads pinned behind each of
+      // this sub-step's first 2 + NF MFMAs.  Left alone the scheduler issues the reads as a burst in front of the MFMAs, and
+      // a wave's matrix pipe waits for its own LDS issue (ubench_tile, rotated 8-wave loop: 3 355 -> 3 146-3 212 cycles a k-step).
+      if (ROT && NF >= 2 && kk + 1 < SUB) {
+#pragma unroll
+        for (int i = 0; i < 2 + NF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x8, 2 * NF - 2 - NF, 0);
+      }
+#endif
 #else
 #pragma unroll
       for (int ni = 0; ni < NF; ++ni)

@@ -100,6 +100,12 @@ struct fdnn_ctx {
   uint32_t *d_chain_ctl = nullptr;   // chained hidden layers (fdnn_chain.hip): queue heads [0..7], workgroups that left [8]
   uint32_t *d_chain_done = nullptr;  // [frame tiles][layers of the chain] node tiles finished; zero between launches
   long long *d_chain_clk = nullptr;  // measurement builds only: per-task phase clocks
+  // A chained launch whose wait ran into its bound has computed on rows that may not have been written: it raises this
+  // host-visible word (fine-grained pinned memory, plain store from the kernel).  run_hidden looks at it before every
+  // launch -- counters re-zeroed, the context never chains again -- and the calls that synchronise anyway re-run the pass.
+  unsigned long long *h_chain_fault = nullptr, *d_chain_fault = nullptr;
+  bool chain_broken = false;
+  size_t chain_done_bytes = 0;
   int chain_clk_cap = 0;
   float *d_l0_dbg_t = nullptr, *d_l0_dbg_dd = nullptr;  // fdnn_debug_layer0_screen only: the int8 screening's t~ and Dd per output
   uint64_t *d_mask_bits = nullptr;  // [n][ceil(O/64)] the batched lazy call's mask as bits (launch_mask_pack)

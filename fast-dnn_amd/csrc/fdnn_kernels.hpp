@@ -149,7 +149,7 @@ void launch_qgemm_output(const QGemmParams &p, hipStream_t s);
 // An int8 hidden layer of a large batch with the two waves of every SIMD in different roles (fdnn_pp.hip): one computes
 // (fragment reads + MFMAs only) while its partner stages that tile's operands and runs the epilogue of the tile it computed
 // before.  256-node x 320-frame tiles (n_pad a multiple of qpp_frame_tile()), K = 2048, validated 3-operation division.
-bool qpp_ok(int rows_pad, int K, int n, bool fastdiv);
+bool qpp_ok(int rows_pad, int K, int n, bool fastdiv, bool has_fix);
 void qpp_set_mode(int mode, int min_frames);  // fdnn_debug_set_pp
 int qpp_frame_tile();
 void launch_qpp_hidden(const QGemmParams &p, hipStream_t s);
@@ -175,7 +175,8 @@ struct QChainParams {
   int frame_tile;          // 320 or 256
   uint32_t *ctl;           // [16]: queue heads [0..7], workgroups that have left [8]; zero between launches
   uint32_t *done;          // [n_pad / frame_tile][n_layers] node tiles finished; zero between launches
-  unsigned long long *faults;  // waits that ran into their bound (never; observable through fdnn_model_fuse_giveups' sibling)
+  unsigned long long *faults;  // waits that ran into their bound (never in a healthy setup): counted, fdnn_model_chain_faults
+  unsigned long long *fault_flag;  // host-visible word of the launching context, raised with the count (null: not raised)
   long long *clk;          // measurement builds (FDNN_CHAIN_CLK): [8 + clk_cap * 10] phase clocks per task, else null
   int clk_cap;
 };

@@ -39,6 +39,9 @@
 #ifndef FDNN_PP_CLK
 #define FDNN_PP_CLK 0  // 1 (measurement builds): printf of per-phase clocks from a few workgroups
 #endif
+#ifndef FDNN_PP_PIPE
+#define FDNN_PP_PIPE 0  // 2: the epilogue's three stages alternate with the tick's weight pieces (the pieces' issue time covers the LDS round trips); 1: a tick's table gathers are packed and parked in the NEXT tick (they return under the barrier); 0: in the same tick
+#endif
 #ifndef FDNN_PP_DEBUG
 #define FDNN_PP_DEBUG 0  // timing experiments: 1 no epilogue arithmetic, 2 no MFMAs, 4 no operand loads, 8 no stores
 #endif
@@ -46,9 +49,9 @@
 namespace fdnn {
 namespace {
 
-constexpr int kNF = 5, kBK = 128, kBM = 256, kHT = 32 * kNF, kFT = 2 * kHT, kKT = 16, kTS = kBM + 16;
-constexpr int kWStages = 3;
-constexpr int kLutBytes = (kLut2Size + 15) & ~15;
+[[maybe_unused]] constexpr int kNF = 5, kBK = 128, kBM = 256, kHT = 32 * kNF, kFT = 2 * kHT, kKT = 16, kTS = kBM + 16;
+[[maybe_unused]] constexpr int kWStages = 3;
+[[maybe_unused]] constexpr int kLutBytes = (kLut2Size + 15) & ~15;
 
 template <bool NOFIX>
 __global__ __launch_bounds__(512, 2) void qpp_kernel(QGemmParams p) {
@@ -359,14 +362,17 @@ __global__ __launch_bounds__(512, 2) void qpp_kernel(QGemmParams p) {
       // (An LDS round trip beside the partner's fragment reads and the LDS-DMA writes is ~400 cycles; unpipelined, two of
       // them per item, the epilogue cost 33 k cycles a phase; one per tick, 10 k.)
       uint32_t gb[3][4];  // gathered table bytes of the previous tick's items
-      auto epi_math = [&](int it0, int it1) {
+      auto epi_bias = [&](v4f_t (&bq)[3], int it0, int it1) {
+#pragma unroll
+        for (int it = it0; it < it1; ++it) bq[it - it0] = *reinterpret_cast<const v4f_t *>(bias_l + 32 * ((it >> 2) & 1) + 8 * (it & 3));
+      };
+      auto epi_math = [&](const v4f_t (&bq)[3], int it0, int it1) {
 #if !(FDNN_PP_DEBUG & 1)
         int idx[3][4];
 #pragma unroll
         for (int it = it0; it < it1; ++it) {
           const int ni = it >> 3, mi = (it >> 2) & 1, g = it & 3;
-          const v4f_t b4 = *reinterpret_cast<const v4f_t *>(bias_l + 32 * mi + 8 * g);
-          const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
+          const float bj[4] = {bq[it - it0].x, bq[it - it0].y, bq[it - it0].z, bq[it - it0].w};
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) {
             const int av = acc[mi][ni][g * 4 + qq];
@@ -380,6 +386,7 @@ __global__ __launch_bounds__(512, 2) void qpp_kernel(QGemmParams p) {
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) gb[it - it0][qq] = lut_s[idx[it - it0][qq]];
 #else
+        (void)bq;
         (void)it0;
         (void)it1;
 #endif
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void qpp_kernel(QGemmParams p) {
           const int T = gt0 + kt;
           bool wq = false;  // this tick ends with eight weight pieces that its wait leaves in flight
           constexpr int kSched[17] = {0, 3, 6, 8, 11, 14, 16, 19, 22, 24, 27, 30, 32, 35, 38, 40, 40};
-          if (evalid && kt >= 1) epi_park(kSched[kt - 1], kSched[kt]);  // (tick 15 parks the last two items)
+          if (FDNN_PP_PIPE == 1 && evalid && kt >= 1) epi_park(kSched[kt - 1], kSched[kt]);  // (tick 15 parks the last two items)
           // ---- (a) the activation rows of the next tick (needed at this tick's barrier: first in the queue)
 #if !(FDNN_PP_DEBUG & 4)
           if (kt < kKT - 1) {
@@ -427,28 +434,50 @@ __global__ __launch_bounds__(512, 2) void qpp_kernel(QGemmParams p) {
           }
 #endif
           // ---- (b) my epilogue: 8 items per 3 ticks (3, 3, 2), parked a tick later: block ni is complete before the barrier of tick 3 ni + 3
-          if (evalid && kt < 15) epi_math(kSched[kt], kSched[kt + 1]);
+          // PIPE 2: bias reads | weight pieces 0..3 | arithmetic, gathers | pieces 4..7 | pack, park -- a wave issues in order, and
+          // the pieces' issue time (~80 cycles each) is what covers the two LDS round trips
+          const bool do_epi = evalid && kt < 15;
+          v4f_t bq[3];
+          if (do_epi && FDNN_PP_PIPE != 3) epi_bias(bq, kSched[kt], kSched[kt + 1]);
+          if (do_epi && FDNN_PP_PIPE < 2) {
+            epi_math(bq, kSched[kt], kSched[kt + 1]);
+            if (!FDNN_PP_PIPE) epi_park(kSched[kt], kSched[kt + 1]);
+          }
           // ---- (c) the weights two ticks ahead (youngest in the queue: the tick's wait leaves them in flight)
 #if !(FDNN_PP_DEBUG & 4)
-          if (kt < kKT - 2) {
-            if (cvalid) {
+          const bool w_cur = kt < kKT - 2 && cvalid, w_nxt = kt >= kKT - 2 && nvalid;
+          wq = w_cur || w_nxt;
+          const __amdgpu_buffer_rsrc_t rw_t = w_nxt ? rw_next() : rw;
+          const int w_chunk = kt < kKT - 2 ? kt + 2 : kt - (kKT - 2);
+          __builtin_amdgcn_sched_barrier(0);
+          if (wq) {
 #pragma unroll
-              for (int i = 0; i < 8; ++i) stage_w(rw, kt + 2, (T + 2) % kWStages, i);
-              wq = true;
-            }
-          } else if (nvalid) {
-            const __amdgpu_buffer_rsrc_t rw_n = rw_next();
-#pragma unroll
-            for (int i = 0; i < 8; ++i) stage_w(rw_n, kt - (kKT - 2), (T + 2) % kWStages, i);
-            wq = true;
+            for (int i = 0; i < 4; ++i) stage_w(rw_t, w_chunk, (T + 2) % kWStages, i);
           }
+          __builtin_amdgcn_sched_barrier(0);
+          if (do_epi && FDNN_PP_PIPE >= 2) {
+            if (FDNN_PP_PIPE == 3) epi_bias(bq, kSched[kt], kSched[kt + 1]);
+            epi_math(bq, kSched[kt], kSched[kt + 1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (wq) {
+#pragma unroll
+            for (int i = 4; i < 8; ++i) stage_w(rw_t, w_chunk, (T + 2) % kWStages, i);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (do_epi && FDNN_PP_PIPE >= 2) epi_park(kSched[kt], kSched[kt + 1]);
 #endif
-          if (wq) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // everything but the youngest weight stage (first tick: also the stores of my compute phase)
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          // everything but the youngest weight stage (first tick: also the stores of my compute phase).  The BUILTIN: with the wait
+          // hidden in inline asm the compiler's own bookkeeping never sees a load retire, and it protects every reuse of a register
+          // that a (scratch) load once wrote with a vmcnt wait of its own -- in front of this tick's pieces, i.e. a full stall.
+          if (wq) __builtin_amdgcn_s_waitcnt(0x0f78);  // vmcnt(8)
+          else __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
+          asm volatile("" ::: "memory");
           // my block bytes (parked at the top of the tick) are in tile_s: LDS operations complete in order, so at most the 12
           // gathers issued since may still be out (scalar loads share the counter and return out of order, but every completion
           // that is not one of them is an older LDS operation: the count still guarantees the stores)
-          asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+          if (FDNN_PP_PIPE == 1) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
         }
@@ -514,20 +543,25 @@ void qpp_set_mode(int mode, int min_frames) {
 }
 
 // The role-split kernel serves the production shape (K = 2048: 16 ticks per phase, 256-node tiles, validated 3-operation
-// division) from `min_frames` up; everything else keeps fdnn_gemm.hip's shapes.
-bool qpp_ok(int rows_pad, int K, int n, bool fastdiv) {
+// division).  Where it pays today (profiles/LABBOOK.md, round 6): layers WITHOUT saturating pairs from two tiles per
+// workgroup up (16 384 frames on a 2048-wide net: 463 vs 480 us for six layers at 20 000 frames; 260 vs 258 at 10 000, where a
+// workgroup has one tile and nothing hides the second half's epilogue).  With the pair-saturation walk in the compute
+// role's instruction stream -- one wave per SIMD, nothing to cover its latency chain -- it loses (328 vs 279 us on the
+// Gaussian bench net): such layers keep fdnn_gemm.hip's in-phase tiles unless forced (fdnn_debug_set_pp(1, n), FDNN_PP=1).
+bool qpp_ok(int rows_pad, int K, int n, bool fastdiv, bool has_fix) {
   static const int env_mode = [] {
     const char *e = std::getenv("FDNN_PP");
     return e ? std::atoi(e) : -1;
   }();
   static const int env_min = [] {
     const char *e = std::getenv("FDNN_PP_MIN");
-    return e ? std::atoi(e) : 8193;
+    return e ? std::atoi(e) : 16384;
   }();
   const int forced = g_pp_mode.load(std::memory_order_relaxed), forced_min = g_pp_min.load(std::memory_order_relaxed);
   const int mode = forced >= 0 ? forced : env_mode;
   const int min_frames = (forced >= 0 && forced_min > 0) ? forced_min : env_min;
   if (mode == 0 || !fastdiv || K != kKT * kBK || rows_pad % kBM != 0) return false;
+  if (mode != 1 && has_fix) return false;
   return n >= min_frames;
 }
 

@@ -10,7 +10,9 @@
 #include <immintrin.h>
 #include <emmintrin.h>
 #include <fcntl.h>
+#include <cerrno>
 #include <sys/file.h>
+#include <sys/stat.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -19,6 +21,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cerrno>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -173,6 +176,7 @@ void destroy_ctx(fdnn_ctx *c) {
   hipFree(c->d_chain_ctl);
   hipFree(c->d_chain_done);
   hipFree(c->d_chain_clk);
+  if (c->h_chain_fault) hipHostFree(c->h_chain_fault);
   hipFree(c->d_l0_dbg_t);
   hipFree(c->d_l0_dbg_dd);
   if (c->h_mask_pin) hipHostFree(c->h_mask_pin);
@@ -242,8 +246,13 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
     const size_t tiles = npt / 256 + 2;
     alloc(reinterpret_cast<void **>(&c->d_chain_ctl), sizeof(uint32_t) * 16);
     alloc(reinterpret_cast<void **>(&c->d_chain_done), sizeof(uint32_t) * tiles * fdnn::kMaxChainLayers);
+    c->chain_done_bytes = sizeof(uint32_t) * tiles * fdnn::kMaxChainLayers;
     if (e == hipSuccess) e = hipMemset(c->d_chain_ctl, 0, sizeof(uint32_t) * 16);
     if (e == hipSuccess) e = hipMemset(c->d_chain_done, 0, sizeof(uint32_t) * tiles * fdnn::kMaxChainLayers);
+    if (e == hipSuccess && hipHostMalloc(reinterpret_cast<void **>(&c->h_chain_fault), sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+      *c->h_chain_fault = 0;
+      if (hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_chain_fault), c->h_chain_fault, 0) != hipSuccess) c->d_chain_fault = nullptr;
+    }
   }
   if (e == hipSuccess && !lean)  // (at least one padded row of slack)
     e = hipHostMalloc(reinterpret_cast<void **>(&c->h_mask_pin), std::max(size_t(kPinFrames) * h.out_dim, size_t(max_rows_pad)), hipHostMallocMapped);
@@ -397,7 +406,15 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
   // Large batches, no taps: the int8 hidden layers as ONE persistent launch (fdnn_chain.hip) -- tasks (layer, frame tile,
   // node tile) drawn from per-XCD queues, each waiting only for its own frame tile's node tiles of the layer before.
   const int n_hid = h.n_q - 1;
-  bool chain = !taps && n_hid >= 2 && c->d_chain_ctl != nullptr &&
+  // (advisor, round 5) a chained launch of this context ran into its wait bound: its counters are dirty and its results
+  // were wrong.  Re-zero the counters in stream order and never chain on this context again; the host-synchronising dense
+  // call re-runs its pass (calculate_on_one_device), the others observe fdnn_model_chain_faults.
+  if (c->h_chain_fault && __atomic_load_n(c->h_chain_fault, __ATOMIC_RELAXED) != 0 && !c->chain_broken) {
+    c->chain_broken = true;
+    (void)hipMemsetAsync(c->d_chain_ctl, 0, sizeof(uint32_t) * 16, s);
+    (void)hipMemsetAsync(c->d_chain_done, 0, c->chain_done_bytes, s);
+  }
+  bool chain = !taps && n_hid >= 2 && c->d_chain_ctl != nullptr && !c->chain_broken &&
                fdnn::qchain_ok(h.q[0].rows_pad, h.q[0].cols_pad - fdnn::kRowSkew, c->n, std::min(n_hid, fdnn::kMaxChainLayers));
   for (int qi = 0; chain && qi < n_hid; ++qi)
     chain = h.q[qi].fastdiv_ok && h.q[qi].rows == h.q[0].rows && h.q[qi].rows_pad == h.q[0].rows_pad && h.q[qi].cols_pad == h.q[0].cols_pad;
@@ -432,6 +449,7 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
       g.ctl = c->d_chain_ctl;
       g.done = c->d_chain_done;
       g.faults = m->d_l0_stats ? m->d_l0_stats + 3 : nullptr;
+      g.fault_flag = c->d_chain_fault;
       g.clk = c->d_chain_clk;
       g.clk_cap = c->chain_clk_cap;
       {
@@ -452,7 +470,7 @@ int run_hidden(fdnn_ctx *c, const float *d_x, hipStream_t s, const Taps *taps) {
     // Large batches of the production shape: the role-split kernel (fdnn_pp.hip) -- one wave of each SIMD in the k-loop,
     // its partner staging that tile's operands and running the epilogue of the tile before.  Identical bytes.
     static const int pp_only = [] { const char *e = std::getenv("FDNN_PP_ONLY"); return e ? std::atoi(e) : -1; }();
-    const bool pp = !g.tap_acc && fdnn::qpp_ok(g.rows_pad, g.K, c->n, g.fastdiv != 0) && (pp_only < 0 || pp_only == qi);
+    const bool pp = !g.tap_acc && fdnn::qpp_ok(g.rows_pad, g.K, c->n, g.fastdiv != 0, g.fix_ent != nullptr) && (pp_only < 0 || pp_only == qi);
     if (pp) {
       g.small = 0;
       g.frame_tile = fdnn::qpp_frame_tile();
@@ -496,17 +514,24 @@ static int device_marker_state(int device) {  // 1 = this process owns the devic
   if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess || !bus[0]) std::snprintf(bus, sizeof(bus), "dev%d", device);
   for (char *q = bus; *q; ++q)
     if (*q == ':' || *q == '/') *q = '-';
-  for (const char *dir : {"/dev/shm", "/tmp"}) {
-    const std::string path = std::string(dir) + "/fdnn-gpu-" + bus;
-    const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-    if (fd < 0) continue;
-    fchmod(fd, 0666);
-    if (flock(fd, LOCK_EX | LOCK_NB) == 0) return state[d];  // (kept open: the lock lives as long as this process)
-    close(fd);
+  // The marker is ADVISORY (advisor, round 5): a world-writable lock file in a sticky directory.  Never follow a planted
+  // symlink (O_NOFOLLOW), only touch the mode of a regular file this user owns, and do not wander to another directory when
+  // /dev/shm is unusable -- two processes looking in different places would both believe they are alone: "cannot tell" is
+  // treated as SHARED (the unfused soft-max: correct, a little slower) and said once.
+  const std::string path = std::string("/dev/shm/fdnn-gpu-") + bus;
+  const int fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
+  if (fd < 0) {
     state[d] = 0;
-    std::fprintf(stderr, "fast-dnn: another process is scoring on GPU %s: this one runs the unfused soft-max (fdnn_device_shared)\n", bus);
+    std::fprintf(stderr, "fast-dnn: cannot open the device marker %s (%s): assuming GPU %s is shared -- unfused soft-max (FDNN_FUSE_NORM=1 overrides)\n",
+                 path.c_str(), std::strerror(errno), bus);
     return state[d];
   }
+  struct stat st {};
+  if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == geteuid()) fchmod(fd, 0666);
+  if (flock(fd, LOCK_EX | LOCK_NB) == 0) return state[d];  // (kept open: the lock lives as long as this process)
+  close(fd);
+  state[d] = 0;
+  std::fprintf(stderr, "fast-dnn: another process is scoring on GPU %s: this one runs the unfused soft-max (fdnn_device_shared)\n", bus);
   return state[d];
 }
 static std::atomic<int> g_fuse_override{-1};  // fdnn_debug_set_fuse: -1 = by environment / device marker, 0 = never, 1 = always
@@ -832,6 +857,14 @@ int calculate_on_one_device(fdnn_model *m, const float *x, int n, int dim, int b
     if (!rc) rc = run_output(c, 0, n, nullptr, c->d_out, s, nullptr);
     if (!rc) rc = copy_out(out, c->d_out, sizeof(float) * size_t(n) * h.out_dim, s);
     if (rc) hipStreamSynchronize(s);
+    // copy_out has synchronised: did this pass's chained launch run into its wait bound?  Then what it computed on may not have
+    // been written -- run the pass again, layer by layer (run_hidden sees the flag, re-zeroes the counters, stops chaining)
+    if (!rc && c->h_chain_fault && __atomic_load_n(c->h_chain_fault, __ATOMIC_RELAXED) != 0 && !c->chain_broken) {
+      rc = run_hidden(c, c->d_x, s, nullptr);
+      if (!rc) rc = run_output(c, 0, n, nullptr, c->d_out, s, nullptr);
+      if (!rc) rc = copy_out(out, c->d_out, sizeof(float) * size_t(n) * h.out_dim, s);
+      if (rc) hipStreamSynchronize(s);
+    }
   }
   release_ctx(c, s);
   if (rc) return rc;
@@ -1560,6 +1593,16 @@ int fdnn_debug_device_counters(fdnn_model *m, unsigned long long *out, int n) { 
   DeviceGuard g(m->device);
   const hipError_t e = hipMemcpy(out, m->d_l0_stats, sizeof(unsigned long long) * size_t(n), hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("device counters: ") + hipGetErrorString(e));
+  return FDNN_OK;
+}
+
+int fdnn_model_chain_faults(fdnn_model *m, unsigned long long *faults) {
+  if (!m || !faults) return fail(FDNN_E_ARG, "null argument");
+  *faults = 0;
+  if (!m->d_l0_stats) return FDNN_OK;
+  DeviceGuard g(m->device);
+  const hipError_t e = hipMemcpy(faults, m->d_l0_stats + 3, sizeof(*faults), hipMemcpyDeviceToHost);  // (synchronizes with the device)
+  if (e != hipSuccess) return fail(FDNN_E_DEVICE, std::string("chain_faults: ") + hipGetErrorString(e));
   return FDNN_OK;
 }
 

@@ -303,7 +303,7 @@ FDNN_API int fdnn_debug_set_chain(int mode, int min_frames);
 /* How a large batch's int8 hidden layers run when they are launched layer by layer: 1 = the role-split kernel (fdnn_pp.hip:
  * one wave of each SIMD in the k-loop, its partner staging that tile's operands and running the previous tile's epilogue)
  * for batches of at least min_frames frames (<= 0: the default threshold), 0 = fdnn_gemm.hip's in-phase tiles, -1 = the
- * default (FDNN_PP / FDNN_PP_MIN in the environment, else on from 8 193 frames).  Process-wide; identical bytes either way.
+ * default (FDNN_PP / FDNN_PP_MIN in the environment, else: layers without saturating pairs from 16 384 frames).  Process-wide; identical bytes either way.
  * QuantizedLayerActivations + AddBias + QuantizedSigmoid, src/cpp/dnn.cc:250-349, is what is being computed. */
 FDNN_API int fdnn_debug_set_pp(int mode, int min_frames);
 
@@ -341,6 +341,14 @@ FDNN_API int fdnn_device_shared(int device);
  * milliseconds late.  *tiles = how many tiles that has happened to on this model since load (0 in a healthy setup).
  * SoftMax::apply, src/cpp/dnn.cc:534-544, is what is being computed. */
 FDNN_API int fdnn_model_fuse_giveups(fdnn_model *m, unsigned long long *tiles);
+/* Chained hidden layers health counter (fdnn_chain.hip: the int8 hidden layers of a large batch in one persistent launch,
+ * a task waiting -- bounded, seconds -- only for its own frame tile's node tiles of the layer before).  *faults = waits that
+ * ran into their bound on this model since load: 0 in a healthy setup; non-zero means a launch computed on rows that may
+ * not have been written (counters left dirty by a killed launch, a wedged device).  The context that saw it re-zeroes its
+ * counters and stops chaining; fdnn_calculate re-runs the affected pass before it returns; callers of the *_device entry
+ * points, which do not synchronise, read this after their own synchronisation.
+ * CalculateUntilLastHiddenLayer's layer loop, src/cpp/dnn.cc:413-423, is what is being computed. */
+FDNN_API int fdnn_model_chain_faults(fdnn_model *m, unsigned long long *faults);
 /* The model's raw device counter words, n <= 32 ([1] layer-0 outputs recomputed, [2] fused soft-max give-ups; kernel clock
  * stamps of timing builds from [4]).  Measurements only. */
 FDNN_API int fdnn_debug_device_counters(fdnn_model *m, unsigned long long *out, int n);

@@ -35,6 +35,12 @@ def test_bench_starts_its_own_two_ranks():
     # whole-job value: both ranks' frames over the slowest rank's time
     assert res["config"]["global_frames"] == 2 * res["config"]["frames_per_gpu"]
     assert res["value"] <= 2 * m["per_rank_frames_per_s"]["max"] * 1.001
+    # the host-fed legs of the N-rank line (round 6): per-rank caller threads and the one-process group, beside `value`
+    hf = res["host_fed"]
+    assert len(hf["per_rank_utterances_per_s"]) == 2 and hf["caller_threads_per_rank"] == 4 and hf["frames_per_utterance"] == 100
+    assert hf["utterances_per_s_whole_node"] <= sum(hf["per_rank_utterances_per_s"]) * 1.001
+    assert hf["frames_per_s_whole_node"] == pytest.approx(100 * hf["utterances_per_s_whole_node"], rel=1e-3)
+    assert res["one_process_group"]["devices"] == 2 and res["one_process_group"]["frames_per_s_whole_node"] > 0
 
 
 def test_bench_single_rank_needs_no_launcher():

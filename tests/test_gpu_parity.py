@@ -438,6 +438,28 @@ def test_shard_of_the_million_frame_config(net_model_path):
     dnn.delete()
 
 
+def test_shard_of_the_million_frame_config_one_row_in_eight(net_model_path):
+    """configs[4], one full 125 000-frame shard of DISTINCT frames: the last hidden layer's u8 activations of every eighth row
+    (15 625 rows: every 320-frame tile, every position modulo 8 inside the 32-frame MFMA blocks over the shard) against the
+    oracle bit for bit, and the probabilities of every 64th row to 2e-6 (dnn.cc:402-454)."""
+    n = 125_000
+    x = F.synth_features(n, 432, seed=131)
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    ctx = dnn.getNewLazyContext(n)
+    ctx.calculateUntilOutput(x)
+    hid = ctx.hiddenActivations()
+    orc = Oracle(net_model_path)
+    rows = np.arange(0, n, 8) + (np.arange(0, n, 8) // 8) % 8  # stride 8 with a rotating phase: all positions mod 8
+    rows = rows[rows < n]
+    want = orc.hidden_acts_mt(x[rows])
+    assert np.array_equal(hid[rows], want)
+    sub = rows[::8]
+    ctx.delete()
+    p = dnn.calculate(x[sub])  # (a batch of its own: scoring does not depend on the batch a frame arrives in -- asserted above)
+    assert np.abs(p - orc.output_mt(want[::8])).max() <= TIGHT
+    dnn.delete()
+
+
 @pytest.mark.parametrize("hidden", [64, 144, 400])
 def test_big_batch_small_net_takes_the_8_wave_shapes(tmp_models, hidden):
     """Enough frames that the 256/320-frame, 8-wave kernel shapes (rotated-barrier k-loop) are

@@ -73,6 +73,14 @@ __global__ __launch_bounds__(128 * WM, 1) void tile_kernel(P p) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[set][mi], b[set][ni], acc[mi][ni], 0, 0, 0);
       if (!(FLAGS & 2)) __builtin_amdgcn_s_setprio(0);
+      if (FLAGS & 8) {  // round 6 (tools/ubench_role.hip): one fragment read pinned behind each of the first MI + NF MFMAs
+#pragma unroll
+        for (int i = 0; i < MI + NF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x8, MI * NF - MI - NF, 0);
+      }
     };
     constexpr int d0 = DIST / 1000, d1 = DIST / 100 % 10, d2 = DIST / 10 % 10;  // loads after the barrier, before ss0, ss1, (ss2)
     if (KT > 1) {
@@ -86,6 +94,7 @@ __global__ __launch_bounds__(128 * WM, 1) void tile_kernel(P p) {
       const bool refill = kt >= 1 && kt + 1 < KT;  // stage kt+1 goes into the buffer freed at the previous barrier
 #pragma unroll
       for (int kk = 0; kk < 3; ++kk) {
+        if (FLAGS & 8) __builtin_amdgcn_sched_barrier(0);
         load_frags(kt, kk + 1, (kk + 1) & 1);
         if (refill) {
           const int lo = kk == 0 ? d0 : kk == 1 ? d0 + d1 : d0 + d1 + d2;
@@ -185,7 +194,13 @@ int main() {
   char *w, *a; long long *out;
   hipMalloc(&w, (size_t)2048 * 2048); hipMalloc(&a, (size_t)10240 * 2048); hipMalloc(&out, 512 * 8);
   hipMemset(w, 1, (size_t)2048 * 2048); hipMemset(a, 2, (size_t)10240 * 2048);
-  run<4, 2, 3222, 0>("8 waves 64x160, loads 3/2/2/2 (ships)", w, a, out);
+  run<4, 2, 3330, 6>("8 waves, ROTATED, 3/3/3/0, no setprio (ships)", w, a, out);
+  run<4, 2, 3330, 14>("8 waves, ROTATED, 3/3/3/0, reads pinned behind the MFMAs", w, a, out);
+  run<4, 2, 5400, 14>("8 waves, ROTATED, 5/4/0/0, reads pinned", w, a, out);
+  run<4, 2, 9000, 14>("8 waves, ROTATED, 9/0/0/0, reads pinned", w, a, out);
+  run<4, 2, 2340, 14>("8 waves, ROTATED, 2/3/4/0, reads pinned", w, a, out);
+  run<4, 2, 3330, 12>("8 waves, ROTATED, 3/3/3/0, reads pinned, setprio", w, a, out);
+  run<4, 2, 3222, 0>("8 waves 64x160, loads 3/2/2/2 (classic)", w, a, out);
   run<4, 2, 9000, 0>("8 waves, loads 9/0/0/0", w, a, out);
   run<4, 2, 5400, 0>("8 waves, loads 5/4/0/0", w, a, out);
   run<4, 2, 3330, 0>("8 waves, loads 3/3/3/0", w, a, out);
