@@ -19,7 +19,7 @@ pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INS
 pass fetch FETCH_SIZE GRBM_GUI_ACTIVE
 pass write WRITE_SIZE
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
-python - $OUT/${TAG}_small_${N}_pmc.json ${P}_pmc_sq/p_counter_collection.csv ${P}_pmc_fetch/p_counter_collection.csv ${P}_pmc_write/p_counter_collection.csv ${P}_pmc_tcc/p_counter_collection.csv <<'PY'
+python $ROOT/tools/small_pmc_summary.py $OUT/${TAG}_small_${N}_pmc.json ${P}_pmc_sq/p_counter_collection.csv ${P}_pmc_fetch/p_counter_collection.csv ${P}_pmc_write/p_counter_collection.csv ${P}_pmc_tcc/p_counter_collection.csv <<'PY'
 import csv, json, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sys.argv[2:]:
