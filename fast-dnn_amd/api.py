@@ -62,6 +62,7 @@ SIGNATURES = {
     "fdnn_debug_set_chain": (C.c_int, [C.c_int, C.c_int]),
     "fdnn_model_chain_faults": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "fdnn_debug_set_pp": (C.c_int, [C.c_int, C.c_int]),
+    "fdnn_debug_set_ppo": (C.c_int, [C.c_int]),
     "fdnn_device_shared": (C.c_int, [C.c_int]),
     "fdnn_debug_set_fuse": (C.c_int, [C.c_int]),
     "fdnn_debug_set_l0_list_cap": (C.c_int, [C.c_void_p, C.c_int]),
@@ -222,6 +223,12 @@ def set_pp(mode: int, min_frames: int = 0) -> None:
     """How a large batch's int8 hidden layers run when launched layer by layer (process-wide; results are bit-identical):
     1 = the role-split kernel (fdnn_pp.hip) for batches of at least min_frames frames, 0 = the in-phase tiles, -1 = default."""
     _check(lib().fdnn_debug_set_pp(int(mode), int(min_frames)))
+
+
+def set_ppo(mode: int) -> None:
+    """How a large dense batch's output layer runs when its soft-max is fused (process-wide; results are bit-identical):
+    1 = the role-split kernel (fdnn_ppo.hip) whenever the shape allows, 0 = the in-phase fused tiles, -1 = default."""
+    _check(lib().fdnn_debug_set_ppo(int(mode)))
 
 
 class LazyContext:

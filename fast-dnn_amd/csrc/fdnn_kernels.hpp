@@ -153,6 +153,12 @@ bool qpp_ok(int rows_pad, int K, int n, bool fastdiv, bool has_fix);
 void qpp_set_mode(int mode, int min_frames);  // fdnn_debug_set_pp
 int qpp_frame_tile();
 void launch_qpp_hidden(const QGemmParams &p, hipStream_t s);
+// fdnn_ppo.hip: the same role split for the OUTPUT layer of a large dense batch, soft-max scaled inside the kernel (the
+// caller holds the device's chain of fused launches: run_output)
+bool qppo_ok(int rows, int rows_pad, int K, int n, bool fastdiv, bool has_fix);
+void qppo_set_mode(int mode);  // -1 default (FDNN_PPO in the environment, else by size), 0 never, 1 whenever the shape allows
+int qppo_frame_tile();
+void launch_qppo_output(const QGemmParams &p, hipStream_t s);
 
 // The int8 HIDDEN layers of a pass in one persistent launch (fdnn_chain.hip): tasks (layer, frame tile, node tile) drawn
 // from per-XCD queues, a task waits only for its own frame tile's node tiles of the layer before.  All hidden layers of

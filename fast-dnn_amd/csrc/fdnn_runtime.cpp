@@ -614,6 +614,13 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   g.acc_probe = taps ? taps->acc_probe : nullptr;
   g.probe_stride = taps ? std::max(1, taps->probe_stride) : 1;
   const bool fused = !c->no_fuse && process_may_fuse(m->device) && fdnn::qgemm_fused_ok(g);  // (taps exclude it; the accumulator probe of the parity tests does not)
+  // the role-split fused kernel (fdnn_ppo.hip): dense, unprobed, the production shape, enough frames for a steady state
+  const bool ppo = fused && !g.mask && !g.mask_bits && !g.acc_probe && fdnn::qppo_ok(d.rows, g.rows_pad, g.K, count, g.fastdiv != 0, g.fix_ent != nullptr);
+  if (ppo) {
+    g.small = 0;
+    g.frame_tile = fdnn::qppo_frame_tile();
+    g.n_pad = round_up(count, g.frame_tile);
+  }
   if (fused) {
     g.final = d_final ? d_final : d_out;
     g.fuse_s = c->d_fuse_s;
@@ -648,7 +655,8 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
         }
         if (fc.recorded) HIP_TRY(hipStreamWaitEvent(s, fc.ev, 0));
       }
-      fdnn::launch_qgemm_output(g, s);
+      if (ppo) fdnn::launch_qppo_output(g, s);
+      else fdnn::launch_qgemm_output(g, s);
       fc.last_stream = s;
       if (stream_is_durable(c, s) && !eager) {
         fc.pending = true;
@@ -1136,6 +1144,12 @@ int fdnn_debug_set_l0_list_cap(fdnn_model *m, int cap) {
 int fdnn_debug_set_pp(int mode, int min_frames) {
   if (mode < -1 || mode > 1) return fail(FDNN_E_ARG, "pp mode must be -1, 0 or 1");
   fdnn::qpp_set_mode(mode, min_frames);
+  return FDNN_OK;
+}
+
+int fdnn_debug_set_ppo(int mode) {
+  if (mode < -1 || mode > 1) return fail(FDNN_E_ARG, "ppo mode must be -1, 0 or 1");
+  fdnn::qppo_set_mode(mode);
   return FDNN_OK;
 }
 
