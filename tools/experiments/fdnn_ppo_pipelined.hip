@@ -1,3 +1,14 @@
+// NOT BUILT, NOT SHIPPED -- the pipelined variant of fdnn_ppo.hip measured in round 6 (profiles/r06_ppo_pipelined.log,
+// profiles/LABBOOK.md): the soft-max of a half exchanged and finished per 32-frame block (block b: exp in ticks 2b, 2b + 1,
+// its 32 x 32 sums published, counted, polled, gathered and summed by compute wave b % 4 in the slots behind the next
+// barriers, scaled and stored by the support waves in ticks 2b + 6, 2b + 7, or in an extension tick when late).  Bit-identical
+// to the in-phase fused tiles at every size tried, and SLOWER than the shipped kernel: 256 vs 223 us (pair-free net, 10 000
+// frames) -- the phases whose blocks were all scaled in time took 72 000 .. 85 000 cycles of ticks (4 500 .. 5 300 a tick)
+// against 34 500 + 17 500 for ticks + extension in the shipped kernel; without the stores still 236 us.  Every step of a
+// block's exchange is a write-through store, a device-scope atomic or a load past the L2s that the issuing wave waits for one
+// tick later (s_waitcnt vmcnt(0)); five blocks per phase multiply those waits, in the wave whose MFMAs the workgroup is waiting for.
+// Host side it needs its own arrival counters (two sets per context, launch k counting in set k & 1 and zeroing the other:
+// QGemmParams::fuse_cnt / fuse_flag), see the patch at the end of this file.
 // fdnn_ppo.hip -- the OUTPUT layer of a large dense batch with the two waves of every SIMD in different roles, soft-max
 // scaled inside the kernel (gfx950).
 //
@@ -35,6 +46,9 @@
 #ifndef FDNN_PPO_CLK
 #define FDNN_PPO_CLK 0  // 1 (measurement builds): printf of per-phase clocks from a few workgroups
 #endif
+#ifndef FDNN_PPO_ST_AUX
+#define FDNN_PPO_ST_AUX 0  // cache policy bits of the probability stores (1 sc0, 2 nt, 16 sc1)
+#endif
 #ifndef FDNN_PPO_DEBUG
 #define FDNN_PPO_DEBUG 0  // timing experiments: 1 no epilogue arithmetic, 2 no MFMAs, 4 no operand loads, 8 no stores, 16 no exchange and no extension, 32 no scale
 #endif
@@ -45,7 +59,14 @@ namespace {
 [[maybe_unused]] constexpr int kNF = 5, kBK = 128, kBM = 256, kHT = 32 * kNF, kFT = 2 * kHT, kKT = 16, kTS = kBM + 16;
 [[maybe_unused]] constexpr int kWStages = 3;
 [[maybe_unused]] constexpr int kMT = 32;       // node tiles of the layer (rows_pad = 8192): the 32 x 160 sums of a half are one 20 KB block
-[[maybe_unused]] constexpr int kPub = 10;      // tick after whose barrier a half's sums are published
+[[maybe_unused]] constexpr int kExpPer = 4;    // epilogue items (of four outputs per lane) per tick: a frame block (32 frames, part b of the half) every two ticks
+// The soft-max of a half is exchanged and finished PER FRAME BLOCK, pipelined through the phase: block b's exp runs in ticks
+// 2b, 2b + 1; its row sums are published behind barrier 2b + 1, counted, polled, gathered and summed by compute wave b % 4
+// in the slots behind the next barriers (ready three ticks later when the siblings are on time); the support waves look
+// for its 1 / total at tick 2b + 6 and scale and store it in ticks 2b + 6, 2b + 7 (four items each) -- or, if it was not
+// there, in an extension tick behind the phase.  The stores of a half so spread over ten ticks beside the partner's MFMAs:
+// all at once behind the phase they are 41 MB that HBM takes 13 000 cycles for, with every matrix core idle (measured).
+[[maybe_unused]] constexpr int kPubTick0 = 1, kSclTick0 = 6;
 [[maybe_unused]] constexpr int kExtBound = 1 << 14;  // extension ticks before a workgroup stops waiting for its siblings (tens of milliseconds)
 
 // ---- the accumulators: in the ACCUMULATION registers a0 .. a159, behind the compiler's back.  A wave's ten 32 x 32 tiles
@@ -244,20 +265,18 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
   // Separate static arrays (fdnn_pp.hip): the compiler must know which LDS traffic can alias an LDS-DMA destination.
   __shared__ __attribute__((aligned(16))) char ringW[kWStages][kBM * kBK];
   __shared__ __attribute__((aligned(16))) char ringA[2][kHT * kBK];
-  // the 32 x 160 row sums of a half (LDS-DMA target of the gather); its first 4 x 160 floats double as the four waves' partial
-  // sums P of the half being exchanged (written with inline asm by the support waves: a plain store to an LDS-DMA target
-  // would make the compiler wait for every load in flight)
-  __shared__ __attribute__((aligned(16))) float sg_s[kMT * kHT];
+  // the 32 node tiles' row sums of a frame block (32 x 32 floats), LDS-DMA target of its gather: block b in buffer b & 3
+  // (blocks 0 and 4 share one: both belong to wave 0, which is done with block 0 long before)
+  __shared__ __attribute__((aligned(16))) float sg_s[4][kMT * 32];
+  __shared__ __attribute__((aligned(16))) float pw_s[4 * kHT];     // the four support waves' partial sums of the half in the epilogue
   __shared__ __attribute__((aligned(16))) float inv_s[kHT];        // RN(1 / total) per frame of the half
   // the workgroup's node tile never changes: its 256 accumulator start values and biases are fetched once
   __shared__ __attribute__((aligned(16))) int wsum_s[kBM];
   __shared__ __attribute__((aligned(16))) float bias_s[kBM];
-  // exchange counters, MONOTONIC over the phases (phase ph's targets are multiples of ph): nothing is ever reset, so a wave that
-  // reads late can only see more.  [0] generation whose sums have all arrived, [1] compute waves whose S stores are out,
-  // [2] ... whose gather pieces have landed, [3] ... that have written their frames' 1 / total, [4] support waves that have scaled
+  // [b] (b < 5): the phase whose frame block b has its 1 / total in inv_s; [5]: frame blocks the support waves have scaled and
+  // stored, MONOTONIC over the phases (20 more per phase: nothing is ever reset, a late reader can only see more)
   __shared__ int xf_s[8];
-  __shared__ __attribute__((aligned(16))) uint32_t xpoll_s[4];  // the polled arrival count lands here (LDS-DMA: no register waits for it)
-
+  __shared__ __attribute__((aligned(16))) uint32_t xpoll_s[8];  // [b]: the polled arrival count of block b lands here (LDS-DMA: no register waits for it)
 #if FDNN_PPO_CLK
   __shared__ long long clk_s[48];  // per phase: start, end of its 16 ticks, end of its extension (wave 0's clock)
   __shared__ int clk_ext[16];
@@ -285,7 +304,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
   const int n_tiles = pair0 < NP ? (NP - pair0 + pair_step - 1) / pair_step : 0;
   if (n_tiles == 0) return;
   auto pair_of = [&](int i) { return pair0 + i * pair_step; };
-  if (tid < 8) xf_s[tid] = 0;
+  if (tid < 8) xf_s[tid] = tid < 5 ? -1 : 0;
+  // this launch's counters (p.fuse_cnt) are zero; the other set (p.fuse_flag), used by the launch before, is zeroed for the next one
+  if (my_mt == 0 && tid < 16)
+    for (int i = 0; i < n_tiles; ++i) p.fuse_flag[16 * pair_of(i) + tid] = 0u;
   if (tid < kBM) {
     wsum_s[tid] = p.wsum[my_mt * kBM + tid];
     bias_s[tid] = p.bias[my_mt * kBM + tid];
@@ -340,90 +362,95 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
         }
       }
 
-      // ---- the exchange of the partner's half (e_half), one step per slot (a slot = the instructions behind a tick's barrier,
-      // or an extension tick): 0 publish S | 1 stores out, arrival | 2 poll | 3 all arrived? | 4 gather | 5 landed | 6 totals
-      int xs = 0;
+      // ---- the exchange of the partner's half (e_half), frame block by frame block: block b is the business of wave b % 4 alone
+      // (its stores, its counter, its poll, its gather: one wave's vector-memory queue, no counting across waves), one step per
+      // slot (a slot = the instructions behind a tick's barrier, or an extension tick):
+      // 0 publish the block's 32 sums | 1 stores out: count, poll | 2 all 32 there? gather : poll again | 3 landed: totals, flag
+      int xs[2] = {0, 0};  // [0]: block wm, [1]: block 4 (wave 0's second)
       float *gs_half = p.fuse_s + static_cast<size_t>(e_half) * kMT * kHT;
-      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.fuse_cnt + 4 * e_half, 0, 16, 0x00020000);
-      uint32_t *cnt = p.fuse_cnt + 4 * e_half;  // [0] node tiles whose sums are out, [1] node tiles that have gathered; zero between launches (four words a half: the context's array is sized for eight per 128 frames)
-      auto xslot = [&]() {
+      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(gs_half, 0, kMT * kHT * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(p.fuse_cnt + 8 * e_half, 0, 32, 0x00020000);
+      auto xpart = [&](int &st, int b) {
+        // (the lane id afresh: every address below is worked out in the slot that needs it, not once per phase and kept --
+        // the k-loop has no registers to spare, and what does not fit is parked in the accumulation registers)
+        int lx = ln;
+        asm volatile("" : "+v"(lx));
+        if (st == 0) {
+          if (lx < 32) {
+            const int t = 32 * b + lx;
+            const float s_ = (pw_s[t] + pw_s[kHT + t]) + (pw_s[2 * kHT + t] + pw_s[3 * kHT + t]);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s_), rg, (my_mt * kHT + t) * 4, 0, 17);  // write-through: read past the other XCDs' L2s
+          }
+          st = 1;
+        } else if (st == 1) {
+          __builtin_amdgcn_s_waitcnt(0x0f70);  // my stores have been acknowledged
+          asm volatile("" ::: "memory");
+          if (lx == 0) {
+            __hip_atomic_fetch_add(p.fuse_cnt + 8 * e_half + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (no return value used: no wait)
+            // the poll is a load INTO LDS, past the L2s: between this slot and the next nothing but the memory system holds it
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, FDNN_LDS_PTR(xpoll_s + b), 4, 0, 4 * b, 0, 17);
+          }
+          st = 2;
+        } else if (st == 2) {
+          __builtin_amdgcn_s_waitcnt(0x0f70);
+          asm volatile("" ::: "memory");
+          uint32_t seen;
+          asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(FDNN_LDS_PTR(xpoll_s + b)))) : "memory");
+          if (__builtin_amdgcn_readfirstlane(seen) >= static_cast<uint32_t>(kMT)) {
+            // the block's 32 x 32 sums: row i of the half's 32, 128 bytes at column 32 b -- eight lanes a row, four instructions
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, FDNN_LDS_PTR(&sg_s[b & 3][j * 256]), 16, (8 * j + (lx >> 3)) * (kHT * 4) + (lx & 7) * 16, 128 * b, 0, 17);
+            st = 3;
+          } else if (lx == 0) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, FDNN_LDS_PTR(xpoll_s + b), 4, 0, 4 * b, 0, 17);
+          }
+        } else if (st == 3) {
+          __builtin_amdgcn_s_waitcnt(0x0f70);
+          asm volatile("" ::: "memory");
+          // adjacent pairs, level by level (normalize_row's tree over the 32 node tiles), depth first, four values at a time
+          // (registers: the k-loop's fragments are alive around this); the lower lanes take node tiles 0 .. 15 of their frame,
+          // the upper lanes 16 .. 31, and the two halves meet in the tree's last addition.  (Inline-assembly reads: a plain
+          // read of an LDS-DMA target makes the compiler wait for every load in flight -- fdnn_pp.hip.)
+          const uint32_t sga = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(FDNN_LDS_PTR(&sg_s[b & 3][0]))) + (lx & 31) * 4 + (lx >> 5) * (16 * 128);
+          float l2[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            float s4[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              float q0, q1, q2, q3;
+              if (c == 0 && d == 0)
+                asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:128\n\tds_read_b32 %2, %4 offset:256\n\tds_read_b32 %3, %4 offset:384\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(sga) : "memory");
+              else if (c == 0)
+                asm volatile("ds_read_b32 %0, %4 offset:512\n\tds_read_b32 %1, %4 offset:640\n\tds_read_b32 %2, %4 offset:768\n\tds_read_b32 %3, %4 offset:896\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(sga) : "memory");
+              else if (d == 0)
+                asm volatile("ds_read_b32 %0, %4 offset:1024\n\tds_read_b32 %1, %4 offset:1152\n\tds_read_b32 %2, %4 offset:1280\n\tds_read_b32 %3, %4 offset:1408\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(sga) : "memory");
+              else
+                asm volatile("ds_read_b32 %0, %4 offset:1536\n\tds_read_b32 %1, %4 offset:1664\n\tds_read_b32 %2, %4 offset:1792\n\tds_read_b32 %3, %4 offset:1920\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(sga) : "memory");
+              s4[d] = (q0 + q1) + (q2 + q3);
+            }
+            l2[c] = s4[0] + s4[1];
+          }
+          const float mine = l2[0] + l2[1];
+          const float other = __int_as_float(__builtin_amdgcn_ds_bpermute((lx ^ 32) << 2, __float_as_int(mine)));
+          const float l3[2] = {mine, other};  // (used by the lower lanes only: tiles 0 .. 15 + tiles 16 .. 31)
+          if (lx < 32) inv_s[32 * b + lx] = 1.0f / (l3[0] + l3[1]);
+          if (lx == 0) xf_s[b] = ph;  // (the same wave's LDS writes keep their order: whoever sees the flag sees the 32 inverses)
+          st = 4;
+        }
+      };
+      // the slot behind barrier kt (kt >= 16: extension ticks): every block of mine whose partial sums are parked by then
+      auto xslot = [&](int kt) {
 #if FDNN_PPO_DEBUG & 16
         return;
 #endif
-        if (xs == 0) {
-          const int t = 64 * wm + ln;
-          if (t < kHT) {
-            const float s_ = (sg_s[t] + sg_s[kHT + t]) + (sg_s[2 * kHT + t] + sg_s[3 * kHT + t]);
-            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(gs_half + static_cast<size_t>(my_mt) * kHT, 0, kHT * 4, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(s_), r, t * 4, 0, 17);  // write-through: read past the other XCDs' L2s
-          }
-          xs = 1;
-        } else if (xs == 1) {
-          __builtin_amdgcn_s_waitcnt(0x0f70);  // my S stores have been acknowledged
-          asm volatile("" ::: "memory");
-          if (ln == 0) {
-            const int old = __hip_atomic_fetch_add(&xf_s[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (old == 4 * ph - 1) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (no return value used: no wait)
-          }
-          xs = 2;
-        } else if (xs == 2) {
-          // the poll is a load INTO LDS, past the L2s: between this slot and the next nothing but the memory system holds
-          // it (an inline-assembly load into a register would be a value the compiler may move before it has arrived)
-          if (wm == 0 && ln == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, FDNN_LDS_PTR(xpoll_s), 4, 0, 0, 0, 17);
-          xs = 3;
-        } else if (xs == 3) {
-          if (wm == 0) {
-            __builtin_amdgcn_s_waitcnt(0x0f70);
-            asm volatile("" ::: "memory");
-            uint32_t seen;
-            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(FDNN_LDS_PTR(xpoll_s)))) : "memory");
-            if (ln == 0) {
-              if (seen >= static_cast<uint32_t>(kMT)) xf_s[0] = ph;
-              else __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, FDNN_LDS_PTR(xpoll_s), 4, 0, 0, 0, 17);
-            }
-          }
-          if (__builtin_amdgcn_readfirstlane(xf_s[0]) == ph) xs = 4;  // (wave 0 goes on at once; the others see the flag behind the next barrier)
-        }
-        if (xs == 4) {
-          // 20 KB, contiguous in memory and in LDS: five one-KiB pieces per wave, past the L2s (sc0 sc1)
-          const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(gs_half, 0, kMT * kHT * 4, 0x00020000);
-#pragma unroll
-          for (int i = 0; i < 5; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, FDNN_LDS_PTR(reinterpret_cast<char *>(sg_s) + (i * 4 + wm) * 1024), 16, ln * 16, (i * 4 + wm) * 1024, 0, 17);
-          xs = 5;
-        } else if (xs == 5) {
-          __builtin_amdgcn_s_waitcnt(0x0f70);
-          asm volatile("" ::: "memory");
-          if (ln == 0) __hip_atomic_fetch_add(&xf_s[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          xs = 6;
-        } else if (xs == 6 && __builtin_amdgcn_readfirstlane(xf_s[2]) >= 4 * ph) {
-          const int t = 64 * wm + ln;
-          if (t < kHT) {  // adjacent pairs, level by level (normalize_row's tree over the 32 node tiles), depth first
-            float l3[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-              float l2[2];
-#pragma unroll
-              for (int b = 0; b < 2; ++b) {
-                const float *q = sg_s + (16 * a + 8 * b) * kHT + t;
-                const float s01 = q[0] + q[kHT], s23 = q[2 * kHT] + q[3 * kHT], s45 = q[4 * kHT] + q[5 * kHT], s67 = q[6 * kHT] + q[7 * kHT];
-                float o = (s01 + s23) + (s45 + s67);
-                asm volatile("" : "+v"(o));
-                l2[b] = o;
-              }
-              l3[a] = l2[0] + l2[1];
-            }
-            inv_s[t] = 1.0f / (l3[0] + l3[1]);
-          }
-          if (wm < 3 && ln == 0) __hip_atomic_fetch_add(&xf_s[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          // one more node tile has gathered: the last one re-zeroes the half's counters.  (After the signal: the support waves
-          // scale while this round trip is out.)
-          if (wm == 0 && ln == 0 && __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == static_cast<uint32_t>(kMT) - 1u) {
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-          xs = 7;
-        }
+        if (kt >= 2 * wm + kPubTick0) xpart(xs[0], wm);
+        if (wm == 0 && kt >= 2 * 4 + kPubTick0) xpart(xs[1], 4);
       };
 
       // fragment i of a sub-step's seven in the order the MFMAs want them: A0 B0 A1 B1 B2 B3 B4
@@ -512,21 +539,23 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        if (evalid && kt >= kPub) xslot();
+        if (evalid) xslot(kt);
         __builtin_amdgcn_sched_barrier(0);
         if (cvalid) substep(true, kt + 1 < kKT, T + 1, 0, 0, 1);
       }
       PPO_CLK(3 * (ph + 1) + 1);
-      // ---- extension ticks: two barriers each (the counters are read between them: nobody adds to one while another wave may
-      // still be reading it for the exit decision), my exchange steps behind the second
+      // ---- extension ticks, only while some support wave has not scaled by the end of tick 15 (late siblings).  The counters
+      // are read in a quiet window (nobody adds to them between the barrier that ends a round and the one that starts the
+      // next): all eight waves take the same decision.
       if (evalid && !(FDNN_PPO_DEBUG & 16)) {
         for (;;) {
+          const bool all_scaled = __builtin_amdgcn_readfirstlane(xf_s[5]) >= 4 * kNF * ph;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (all_scaled || ++ext_iters > kExtBound) break;
           __builtin_amdgcn_s_barrier();
-          const bool all_scaled = __builtin_amdgcn_readfirstlane(xf_s[4]) >= 4 * ph;
+          xslot(kKT);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
-          if (all_scaled || ++ext_iters > kExtBound) break;
-          xslot();
         }
       }
     } else {
@@ -555,7 +584,6 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, FDNN_LDS_PTR(&ringA[buf][slab * 1024]), 16, voff_a, slab * 8 * lda_s + chunk * kBK, 0, 0);
       };
       float psum = 0.0f;
-      const uint32_t pw_a = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(FDNN_LDS_PTR(sg_s))) + (wm * kHT + (ln & 31)) * 4;
       float rcp_s = p.rcp_coef, coef_s = p.coef;
       asm volatile("" : "+s"(rcp_s), "+s"(coef_s));
       auto exp_item = [&](int it) {
@@ -574,13 +602,47 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
         if ((it & 7) == 7) {  // the block's 16 values of this lane are in: + the other half's 16, parked for the publish
           // (the other half's sum by address: __shfl_xor keeps its own copy of the lane id alive across the whole kernel)
           const float tot = psum + __int_as_float(__builtin_amdgcn_ds_bpermute((ln ^ 32) << 2, __float_as_int(psum)));
-          if ((ln >> 5) == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(pw_a + 32 * ni * 4), "v"(tot) : "memory");
+          if ((ln >> 5) == 0) pw_s[wm * kHT + 32 * ni + ln] = tot;
           psum = 0.0f;
         }
 #else
         (void)it;
 #endif
       };
+
+      // p = e * RN(1 / total) on the way out.  One descriptor for the pair's rows that exist (frames past n fall outside
+      // it), one lane offset for all 40 stores: the frame block comes as the scalar offset, the item as a constant; nodes past
+      // the layer's last (the last node tile only) get an offset outside everything.
+      typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+      const int f0 = e_pair * kFT;
+      const int rows_s = p.rows;
+      const __amdgpu_buffer_rsrc_t ro =
+          __builtin_amdgcn_make_buffer_rsrc(p.final + static_cast<size_t>(f0) * rows_s, 0, evalid ? max(0, min(kFT, p.n - f0)) * rows_s * 4 : 0, 0x00020000);
+      const int node0 = my_mt * kBM + 64 * wm + 4 * (ln >> 5);
+      const int lim = rows_s - node0;  // this lane's item at node offset o exists iff o + 4 <= lim
+      const int voff = ((sg * kHT + (ln & 31)) * rows_s + node0) * 4;
+      auto scale_item = [&](int it) {
+#if !(FDNN_PPO_DEBUG & 32)
+        const int ni = it >> 3, mi = (it >> 2) & 1, g = it & 3;
+        const float iv = inv_s[32 * ni + (ln & 31)];
+        v4f_t o4;
+        switch (it) {
+#define X(IT, OFF, R0, R1, R2, R3) \
+  case IT: PPO_SCL4(R0, R1, R2, R3); break;
+          PPO_ITEMS(X)
+#undef X
+          default: break;
+        }
+#if !(FDNN_PPO_DEBUG & 8)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o4), ro, 32 * mi + 8 * g + 4 <= lim ? voff : static_cast<int>(0x80000000u),
+                                               32 * ni * rows_s * 4 + (32 * mi + 8 * g) * 4, FDNN_PPO_ST_AUX);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+#else
+        (void)it;
+#endif
+      };
+      bool sc_go[kNF] = {false, false, false, false, false};  // block b's 1 / total were there at tick 2b + 6: scaled inside the phase
 
 #pragma unroll
       for (int kt = 0; kt < kKT; ++kt) {
@@ -600,13 +662,15 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
           }
 #endif
           __builtin_amdgcn_sched_barrier(0);
-          if (evalid && kt < kPub) {  // my epilogue's arithmetic: four items (one accumulator tile) a tick
+          if (evalid && kExpPer * kt < 8 * kNF) {  // my epilogue's arithmetic: one frame block (two accumulator tiles) a tick
 #pragma unroll
-            for (int it = 4 * kt; it < 4 * kt + 4; ++it) {
+            for (int it = kExpPer * kt; it < kExpPer * kt + kExpPer; ++it) {
               exp_item(it);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
+          const int sb = (kt - kSclTick0) >> 1;  // the frame block whose scale is scheduled for this tick (and the next / the one before)
+          if (evalid && kt >= kSclTick0 && !((kt - kSclTick0) & 1) && !(FDNN_PPO_DEBUG & 16)) sc_go[sb] = __builtin_amdgcn_readfirstlane(xf_s[sb]) == ph;
 #if !(FDNN_PPO_DEBUG & 4)
           const bool w_cur = kt < kKT - 2 && cvalid, w_nxt = kt >= kKT - 2 && nvalid;
           wq = w_cur || w_nxt;
@@ -616,8 +680,27 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
             for (int i = 0; i < 8; ++i) stage_w(rw, w_chunk, (T + 2) % kWStages, i);  // (the node tile never changes: the next half's weights are this tile's)
           }
 #endif
-          if (wq) __builtin_amdgcn_s_waitcnt(0x0f78);  // vmcnt(8)
-          else __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
+          // the scale and its stores go BEHIND the weight pieces in the wave's queue (which completes in order): the tick's wait
+          // leaves them in flight with those, and the activation rows this tick needs are not held up by store acknowledgements
+          const bool sc_now = evalid && kt >= kSclTick0 && sc_go[sb >= 0 ? sb : 0];
+          if (sc_now) {
+            const int lo = 8 * sb + 4 * ((kt - kSclTick0) & 1);
+#pragma unroll
+            for (int it = lo; it < lo + 4; ++it) scale_item(it);
+            if (((kt - kSclTick0) & 1) && ln == 0) __hip_atomic_fetch_add(&xf_s[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          if (sc_now) {
+            if (FDNN_PPO_DEBUG & (8 | 32)) {
+              if (wq) __builtin_amdgcn_s_waitcnt(0x0f78);
+              else __builtin_amdgcn_s_waitcnt(0x0f70);
+            } else {  // weight pieces + this tick's four stores stay in flight
+              if (wq) __builtin_amdgcn_s_waitcnt(0x0f7c);  // vmcnt(12)
+              else __builtin_amdgcn_s_waitcnt(0x0f74);     // vmcnt(4)
+            }
+          } else {
+            if (wq) __builtin_amdgcn_s_waitcnt(0x0f78);  // vmcnt(8)
+            else __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
+          }
           asm volatile("" ::: "memory");
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my partial sums are in LDS
           __builtin_amdgcn_s_barrier();
@@ -625,51 +708,29 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
         }
       }
       PPO_CLK(3 * (ph + 1) + 1);
-      // ---- extension ticks: scale and store once the frames' 1 / total are there
+      // ---- extension ticks (see the compute role): the frame blocks whose totals were not there in time are scaled here
       if (evalid && !(FDNN_PPO_DEBUG & 16)) {
-        bool scaled = false;
+        bool scaled = sc_go[0] && sc_go[1] && sc_go[2] && sc_go[3] && sc_go[4];
         for (;;) {
+          const bool all_scaled = __builtin_amdgcn_readfirstlane(xf_s[5]) >= 4 * kNF * ph;
+          int ready = 0;
+#pragma unroll
+          for (int b = 0; b < kNF; ++b) ready |= (__builtin_amdgcn_readfirstlane(xf_s[b]) == ph ? 1 : 0) << b;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (all_scaled || ++ext_iters > kExtBound) break;
           __builtin_amdgcn_s_barrier();
-          const bool all_scaled = __builtin_amdgcn_readfirstlane(xf_s[4]) >= 4 * ph;
-          const bool inv_ready = __builtin_amdgcn_readfirstlane(xf_s[3]) >= 3 * ph;
+#pragma unroll
+          for (int b = 0; b < kNF; ++b) {
+            if (!sc_go[b] && ((ready >> b) & 1)) {
+#pragma unroll
+              for (int it = 8 * b; it < 8 * b + 8; ++it) scale_item(it);
+              sc_go[b] = true;
+              if (ln == 0) __hip_atomic_fetch_add(&xf_s[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+          scaled = sc_go[0] && sc_go[1] && sc_go[2] && sc_go[3] && sc_go[4];
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
-          if (all_scaled || ++ext_iters > kExtBound) break;
-          if (inv_ready && !scaled) {
-#if !(FDNN_PPO_DEBUG & 32)
-            // one descriptor for the pair's rows that exist (frames past n fall outside it), one lane offset for all 40
-            // stores: the frame block comes as the scalar offset, the item as the immediate; nodes past the layer's last
-            // (the last node tile only) get an offset outside everything
-            typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-            const int f0 = e_pair * kFT;
-            const int rows_s = p.rows;
-            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.final + static_cast<size_t>(f0) * rows_s, 0,
-                                                                                  max(0, min(kFT, p.n - f0)) * rows_s * 4, 0x00020000);
-            const int node0 = my_mt * kBM + 64 * wm + 4 * (ln >> 5);
-            const int lim = rows_s - node0;  // this lane's item at node offset o exists iff o + 4 <= lim
-            const int voff = ((sg * kHT + (ln & 31)) * rows_s + node0) * 4;
-#pragma unroll
-            for (int it = 0; it < 8 * kNF; ++it) {
-              const int ni = it >> 3, mi = (it >> 2) & 1, g = it & 3;
-              const float iv = inv_s[32 * ni + (ln & 31)];
-              v4f_t o4;
-              switch (it) {
-#define X(IT, OFF, R0, R1, R2, R3) \
-  case IT: PPO_SCL4(R0, R1, R2, R3); break;
-                PPO_ITEMS(X)
-#undef X
-                default: break;
-              }
-#if !(FDNN_PPO_DEBUG & 8)
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o4), ro, 32 * mi + 8 * g + 4 <= lim ? voff : static_cast<int>(0x80000000u),
-                                                     32 * ni * rows_s * 4 + (32 * mi + 8 * g) * 4, 0);
-#endif
-              __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
-            scaled = true;
-            if (ln == 0) __hip_atomic_fetch_add(&xf_s[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
         }
         if (!scaled && wm == 0 && ln == 0 && p.fuse_giveups) atomicAdd(p.fuse_giveups, 1ull);  // the siblings never arrived: this half's rows are missing, and it says so
       }
@@ -731,3 +792,55 @@ void launch_qppo_output(const QGemmParams &p, hipStream_t s) {
 }
 
 }  // namespace fdnn
+/* ---- the runtime patch that went with it
+diff --git a/fast-dnn_amd/csrc/fdnn_internal.hpp b/fast-dnn_amd/csrc/fdnn_internal.hpp
+index bc4e785..2a5e5c9 100644
+--- a/fast-dnn_amd/csrc/fdnn_internal.hpp
++++ b/fast-dnn_amd/csrc/fdnn_internal.hpp
+@@ -96,6 +96,9 @@ struct fdnn_ctx {
+   int8_t *d_mask = nullptr;       // [n][O]
+   float *d_fuse_s = nullptr;        // fused soft-max: per-tile row sums [n_pad / tile][rows_pad / 256][tile] floats
+   uint32_t *d_fuse_cnt = nullptr;   // {arrived part 0 .., left at [7]} per frame tile; zero between launches
++  uint32_t *d_ppo_cnt = nullptr;     // fdnn_ppo.hip's arrival counters: two sets of ppo_set_words, launch k counts in set k & 1 and zeroes the other
++  size_t ppo_set_words = 0;
++  unsigned ppo_launches = 0;
+   uint32_t *d_fuse_flag = nullptr;  // per tile: parts a workgroup left unscaled ("gave up waiting"); zero between launches
+   uint32_t *d_chain_ctl = nullptr;   // chained hidden layers (fdnn_chain.hip): queue heads [0..7], workgroups that left [8]
+   uint32_t *d_chain_done = nullptr;  // [frame tiles][layers of the chain] node tiles finished; zero between launches
+diff --git a/fast-dnn_amd/csrc/fdnn_runtime.cpp b/fast-dnn_amd/csrc/fdnn_runtime.cpp
+index 5f4c53f..14a3045 100644
+--- a/fast-dnn_amd/csrc/fdnn_runtime.cpp
++++ b/fast-dnn_amd/csrc/fdnn_runtime.cpp
+@@ -173,6 +173,7 @@ void destroy_ctx(fdnn_ctx *c) {
+   hipFree(c->d_fuse_s);
+   hipFree(c->d_fuse_cnt);
+   hipFree(c->d_fuse_flag);
++  hipFree(c->d_ppo_cnt);
+   hipFree(c->d_chain_ctl);
+   hipFree(c->d_chain_done);
+   hipFree(c->d_chain_clk);
+@@ -239,6 +240,9 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
+     alloc(reinterpret_cast<void **>(&c->d_fuse_s), sizeof(float) * npt * mt);
+     alloc(reinterpret_cast<void **>(&c->d_fuse_cnt), sizeof(uint32_t) * 8 * tiles);
+     alloc(reinterpret_cast<void **>(&c->d_fuse_flag), sizeof(uint32_t) * tiles * mt);
++    c->ppo_set_words = 16 * (npt / 320 + 2);  // fdnn_ppo.hip: per half eight counters, two sets used by alternate launches (each zeroes the other)
++    alloc(reinterpret_cast<void **>(&c->d_ppo_cnt), sizeof(uint32_t) * 2 * c->ppo_set_words);
++    if (e == hipSuccess) e = hipMemset(c->d_ppo_cnt, 0, sizeof(uint32_t) * 2 * c->ppo_set_words);
+     if (e == hipSuccess) e = hipMemset(c->d_fuse_cnt, 0, sizeof(uint32_t) * 8 * tiles);
+     if (e == hipSuccess) e = hipMemset(c->d_fuse_flag, 0, sizeof(uint32_t) * tiles * mt);
+   }
+@@ -655,7 +659,12 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
+         }
+         if (fc.recorded) HIP_TRY(hipStreamWaitEvent(s, fc.ev, 0));
+       }
+-      if (ppo) fdnn::launch_qppo_output(g, s);
++      if (ppo) {
++        const size_t set = c->ppo_launches++ & 1;
++        g.fuse_cnt = c->d_ppo_cnt + set * c->ppo_set_words;
++        g.fuse_flag = c->d_ppo_cnt + (set ^ 1) * c->ppo_set_words;
++        fdnn::launch_qppo_output(g, s);
++      }
+       else fdnn::launch_qgemm_output(g, s);
+       fc.last_stream = s;
+       if (stream_is_durable(c, s) && !eager) {
+*/
