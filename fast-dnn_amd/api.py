@@ -63,6 +63,7 @@ SIGNATURES = {
     "fdnn_model_chain_faults": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong)]),
     "fdnn_debug_set_pp": (C.c_int, [C.c_int, C.c_int]),
     "fdnn_debug_set_ppo": (C.c_int, [C.c_int]),
+    "fdnn_debug_raise_fuse_fault": (C.c_int, [C.c_void_p, C.c_int]),
     "fdnn_device_shared": (C.c_int, [C.c_int]),
     "fdnn_debug_set_fuse": (C.c_int, [C.c_int]),
     "fdnn_debug_set_l0_list_cap": (C.c_int, [C.c_void_p, C.c_int]),
@@ -108,6 +109,7 @@ SIGNATURES = {
     "fdnn_model_export_blob": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "fdnn_model_import_blob": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]),
     "fdnn_debug_frame_chunks": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_int]),
+    "fdnn_debug_frame_chunks_for": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "fdnn_debug_production_acc_out": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, C.c_int, _c_i8p, _c_i32p, _c_f32p]),
     "fdnn_debug_forward_taps": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_i8p, _c_f32p, _c_u8p, _c_i32p, _c_i32p, _c_f32p, _c_f32p]),
     "fdnn_debug_layer0": (C.c_int, [C.c_void_p, _c_f32p, C.c_int, _c_u8p, C.POINTER(C.c_ulonglong)]),
@@ -576,6 +578,10 @@ class QuantizedDnn:
     # -- per-kernel HIP-event timing ------------------------------------------
     PROF_KINDS = ("l0", "fix", "hidden_gemm", "output_gemm", "normalize")
 
+    def raiseFuseFault(self, value: int = 1) -> None:
+        """Tests: as if a fused soft-max launch of this model had just given up its bounded wait (1) / forget it (0)."""
+        _check(lib().fdnn_debug_raise_fuse_fault(self.nativeDnnHandle, int(value)))
+
     def fuseGiveups(self) -> int:
         """Tiles of the fused soft-max that had to be finished by the clean-up kernel since load (fdnn_model_fuse_giveups)."""
         v = C.c_ulonglong(0)
@@ -727,10 +733,11 @@ def host_blob_check(blob: np.ndarray) -> dict:
     return dict(zip(("input_dim", "hidden_dim", "output_dim", "n_affine"), (int(v.value) for v in d)))
 
 
-def frame_chunks(n: int):
-    """(first frame, frame count) of every chunk a pass over ``n`` frames runs as (host logic, no device needed)."""
+def frame_chunks(n: int, chained: bool = True):
+    """(first frame, frame count) of every chunk a pass over ``n`` frames runs as (host logic, no device needed); ``chained``:
+    whether the batch's hidden layers run as one chained launch (if not, a small tail past a whole round is split off)."""
     buf = (C.c_int * 4096)()
-    k = lib().fdnn_debug_frame_chunks(int(n), buf, 2048)
+    k = lib().fdnn_debug_frame_chunks_for(int(n), 1 if chained else 0, buf, 2048)
     if k < 0:
         raise ValueError("fdnn_debug_frame_chunks")
     return [(int(buf[2 * i]), int(buf[2 * i + 1])) for i in range(k)]

@@ -49,6 +49,11 @@ struct fdnn_model {
   int8_t *d_w0d = nullptr;    // int8 screening (fdnn_l0s.hip): the layer-0 weights as three int8 digit planes, MFMA fragment order
   float *d_w0stat = nullptr;  // [3][l0_h_ld]: 2^8 / c_n, ||w_n||_2, 2^8 b_n
   uint32_t *d_lutpair = nullptr;  // the sigmoid table as (round-down, round-up) byte pairs
+  // the device side of "is somebody else scoring on this GPU?".  A fused soft-max workgroup that
+  // sits out its bounded wait (tens of milliseconds: its frame tile's siblings were kept off the chip) raises this
+  // host-mapped word; from the next call on the model runs the scale-pass path, for good, and says so once.
+  unsigned long long *h_fuse_fault = nullptr, *d_fuse_fault = nullptr;
+  bool fuse_fault_said = false;
   unsigned long long *d_l0_stats = nullptr;  // [4] device counters: [1] layer-0 outputs recomputed exactly, [2] fused soft-max tiles that gave up waiting
   int l0_jc = 0, l0_j_pad = 0, l0_h_ld = 0;
   int l0_fma = 0;
@@ -165,10 +170,14 @@ void lazy_expand_rows_from(float *out, const float *comp, int count, size_t O, s
 // 12.09 M frames/s as one batch (4 GB of result rows, 512 MB of activations per layer: the address-translation and Infinity
 // caches stop covering the working set), 12.87 M in chunks of one round, 13.14 M in chunks of two (tools/chunk_bench.py).
 // Returns (offset, count) pairs: chunks of kChunkFrames, then what is left as one more batch.  (Up to round 4 a small tail
-// past a whole round was split off as a batch of its own; the chained hidden layers made that unnecessary: frame_chunks.)
+// past a whole round was always split off as a batch of its own; with chained hidden layers that is unnecessary: frame_chunks.)
 constexpr int kRoundFrames = 10240;
 constexpr int kChunkFrames = 2 * kRoundFrames;
-std::vector<std::pair<int, int>> frame_chunks(int n);
+constexpr int kChunkTailSplit = 2048;
+// With a model: a chunk whose hidden layers will not run as one chained launch (hidden_layers_chain) gives up to
+// kChunkTailSplit frames past a whole round away as a batch of their own.  Without: as assume_chained says.
+std::vector<std::pair<int, int>> frame_chunks(int n, const fdnn_model *m = nullptr, bool assume_chained = true);
+bool hidden_layers_chain(const fdnn_model *m, int n);
 // Ordering between the streams a context is used on.  An event record costs 3-4 us of queue time behind the kernel it
 // follows, so a context whose work went to a stream that is certain to exist later -- its own, its owner's, or the null
 // stream -- only NOTES that (done_pending); the record is made when a different stream next needs the order (ctx_enter),

@@ -126,6 +126,7 @@ struct QGemmParams {
   uint32_t *fuse_flag;
   int fuse_stagger;       // fused soft-max: start delay of the first round's frame tile j = (j % 8) * this many 512-cycle naps (see qgemm_kernel)
   unsigned long long *fuse_giveups;  // per model: tiles that had to be scaled after the fact (a workgroup gave up waiting); null = not counted
+  unsigned long long *fuse_fault;    // per model, HOST memory: raised with the first give-up -- the host then stops fusing for this model (run_output); null = nobody listens
   // accumulator probe of the PRODUCTION output instances (parity tests only; null otherwise): the int32 accumulators of
   // every probe_stride-th frame, [ceil(n / probe_stride)][rows] -- a wave-uniform branch in front of the epilogue
   int32_t *acc_probe;

@@ -671,7 +671,10 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
             if (ln == 0) __hip_atomic_fetch_add(&xf_s[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
         }
-        if (!scaled && wm == 0 && ln == 0 && p.fuse_giveups) atomicAdd(p.fuse_giveups, 1ull);  // the siblings never arrived: this half's rows are missing, and it says so
+        if (!scaled && wm == 0 && ln == 0) {  // the siblings never arrived: this half's rows are missing, and it says so
+          if (p.fuse_giveups) atomicAdd(p.fuse_giveups, 1ull);
+          if (p.fuse_fault) __hip_atomic_store(p.fuse_fault, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
     }
     PPO_CLK(3 * (ph + 1) + 2);

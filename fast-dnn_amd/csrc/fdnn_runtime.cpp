@@ -142,6 +142,13 @@ int build_l0_image(fdnn_model *m) {
     }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&m->d_l0_stats), 32 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(m->d_l0_stats, 0, 32 * sizeof(unsigned long long)));
+    if (hipHostMalloc(reinterpret_cast<void **>(&m->h_fuse_fault), sizeof(unsigned long long), hipHostMallocMapped) == hipSuccess) {
+      *m->h_fuse_fault = 0;
+      if (hipHostGetDevicePointer(reinterpret_cast<void **>(&m->d_fuse_fault), m->h_fuse_fault, 0) != hipSuccess) m->d_fuse_fault = nullptr;
+    } else {
+      (void)hipGetLastError();
+      m->h_fuse_fault = nullptr;
+    }
   }
   HIP_TRY(hipDeviceSynchronize());
   return FDNN_OK;
@@ -535,6 +542,23 @@ static int device_marker_state(int device) {  // 1 = this process owns the devic
   return state[d];
 }
 static std::atomic<int> g_fuse_override{-1};  // fdnn_debug_set_fuse: -1 = by environment / device marker, 0 = never, 1 = always
+// The model's own evidence (see fdnn_model::h_fuse_fault): once a fused launch of this model has given up, it does not fuse again.
+static bool model_may_fuse(fdnn_model *m) {
+  if (!m->h_fuse_fault || __atomic_load_n(m->h_fuse_fault, __ATOMIC_RELAXED) == 0) return true;
+  if (!m->fuse_fault_said) {
+    m->fuse_fault_said = true;
+    std::fprintf(stderr,
+                 "fast-dnn: a fused soft-max launch on GPU %d sat out its bounded wait (another process scoring on this GPU that the device marker "
+                 "did not show?): this model runs the unfused soft-max from here on (fdnn_model_fuse_giveups counts; FDNN_FUSE_NORM=1 overrides)\n",
+                 m->device);
+  }
+  static const bool forced_on = [] {
+    const char *e = std::getenv("FDNN_FUSE_NORM");
+    return e && std::atoi(e) != 0;
+  }();
+  return forced_on || g_fuse_override.load(std::memory_order_relaxed) == 1;
+}
+
 static bool process_may_fuse(int device) {
   const int o = g_fuse_override.load(std::memory_order_relaxed);
   if (o >= 0) return o == 1;
@@ -613,7 +637,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
   g.tap_logit = taps ? taps->logits : nullptr;
   g.acc_probe = taps ? taps->acc_probe : nullptr;
   g.probe_stride = taps ? std::max(1, taps->probe_stride) : 1;
-  const bool fused = !c->no_fuse && process_may_fuse(m->device) && fdnn::qgemm_fused_ok(g);  // (taps exclude it; the accumulator probe of the parity tests does not)
+  const bool fused = !c->no_fuse && process_may_fuse(m->device) && model_may_fuse(m) && fdnn::qgemm_fused_ok(g);  // (taps exclude it; the accumulator probe of the parity tests does not)
   // the role-split fused kernel (fdnn_ppo.hip): dense, unprobed, the production shape, enough frames for a steady state
   const bool ppo = fused && !g.mask && !g.mask_bits && !g.acc_probe && fdnn::qppo_ok(d.rows, g.rows_pad, g.K, count, g.fastdiv != 0, g.fix_ent != nullptr);
   if (ppo) {
@@ -627,6 +651,7 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
     g.fuse_cnt = c->d_fuse_cnt;
     g.fuse_flag = c->d_fuse_flag;
     g.fuse_giveups = m->d_l0_stats ? m->d_l0_stats + 2 : nullptr;
+    g.fuse_fault = m->d_fuse_fault;
     static const int stagger = [] {
       const char *e = FDNN_TUNE_ENV("FDNN_FUSE_STAGGER");
       return e ? std::atoi(e) : 0;
@@ -691,7 +716,7 @@ bool output_will_fuse(fdnn_ctx *c, int count, const int8_t *d_masks) {
   fdnn::QGemmParams g = prepare_qlayer(c, d, c->d_act[0], count, nullptr, true);
   g.mask = d_masks;
   if (d_masks && !g.small) g.mask_bits = c->d_mask_bits;  // (what run_output will do)
-  return process_may_fuse(c->m->device) && fdnn::qgemm_fused_ok(g);
+  return process_may_fuse(c->m->device) && model_may_fuse(c->m) && fdnn::qgemm_fused_ok(g);
 }
 
 // Device -> pageable host memory for large results (the 8000-float rows of a whole batch:
@@ -761,15 +786,41 @@ int acquire_ctx(fdnn_model *m, int n, fdnn_ctx **out) {
 // the context's last enqueued work and ends by recording it: calculateUntilOutputDevice(stream)
 // followed by calculateForOutputNodes() or hiddenActivations() reads finished activations
 // without the caller synchronising anything.  On one stream both calls are no-ops for the device.
-std::vector<std::pair<int, int>> frame_chunks(int n) {
+// Would run_hidden chain the int8 hidden layers of an n-frame batch of this model?  (The context-independent part of its
+// decision: taps and a context whose chain faulted are the caller's business.)
+bool hidden_layers_chain(const fdnn_model *m, int n) {
+  const BlobHeader &h = m->hm.hdr;
+  const int n_hid = h.n_q - 1;
+  if (n_hid < 2) return false;
+  for (int qi = 0; qi < n_hid; ++qi)
+    if (!(h.q[qi].fastdiv_ok && h.q[qi].rows == h.q[0].rows && h.q[qi].rows_pad == h.q[0].rows_pad && h.q[qi].cols_pad == h.q[0].cols_pad)) return false;
+  return fdnn::qchain_ok(h.q[0].rows_pad, h.q[0].cols_pad - fdnn::kRowSkew, n, std::min(n_hid, fdnn::kMaxChainLayers));
+}
+
+std::vector<std::pair<int, int>> frame_chunks(int n, const fdnn_model *m, bool assume_chained) {
   std::vector<std::pair<int, int>> out;
   static const int kChunk = [] {  // FDNN_CHUNK_FRAMES: measurement switch (0 = never chunk; otherwise whole rounds)
     const char *e = std::getenv("FDNN_CHUNK_FRAMES");
     const int v = e ? std::atoi(e) : kChunkFrames;
     return v <= 0 ? 0 : std::max(kRoundFrames, v / kRoundFrames * kRoundFrames);
   }();
+  // A batch whose hidden layers run as a launch per layer (chaining off, fewer than two int8 hidden layers, a layer without
+  // the validated division: hidden_layers_chain says) pays one more, nearly empty round of workgroups in every
+  // layer for a few frames past a whole round -- 11 000 frames as one batch 977 us, as 10 240 + 760: 754 + 150 (rounds 2-4;
+  // advisor, round 5: the split had been dropped for every configuration).  Such a tail (up to kChunkTailSplit frames) goes
+  // as a small batch of its own.
+  auto split_tail = [&](int off, int cnt) {
+    const int tail = cnt % kRoundFrames;
+    const bool chained = m ? hidden_layers_chain(m, cnt) : assume_chained;
+    if (!chained && cnt > kRoundFrames && tail > 0 && tail <= kChunkTailSplit) {
+      out.emplace_back(off, cnt - tail);
+      out.emplace_back(off + cnt - tail, tail);
+    } else {
+      out.emplace_back(off, cnt);
+    }
+  };
   if (kChunk <= 0 || n <= kChunk) {
-    out.emplace_back(0, n);
+    split_tail(0, n);
     return out;
   }
   // Chunks of kChunk frames, what is left over as one more batch.  (Rounds 2-4 kept a batch to whole rounds of workgroups and
@@ -782,9 +833,10 @@ std::vector<std::pair<int, int>> frame_chunks(int n) {
     out.emplace_back(off, kChunk);
     off += kChunk;
   }
-  out.emplace_back(off, n - off);
+  split_tail(off, n - off);
   return out;
 }
+
 
 bool stream_is_durable(const fdnn_ctx *c, hipStream_t s) {
   return s == nullptr || s == c->stream || s == c->durable[0] || s == c->durable[1] || s == c->durable[2];
@@ -991,6 +1043,7 @@ int fdnn_model_load_on(const char *path, float cutoff, int device, fdnn_model **
     if (m->d_w0stat) hipFree(m->d_w0stat);
     if (m->d_lutpair) hipFree(m->d_lutpair);
     if (m->d_l0_stats) hipFree(m->d_l0_stats);
+    if (m->h_fuse_fault) hipHostFree(m->h_fuse_fault);
     delete m;
     return rc;
   }
@@ -1074,6 +1127,7 @@ void fdnn_model_free(fdnn_model *m) {
     hipFree(m->d_w0stat);
     hipFree(m->d_lutpair);
     hipFree(m->d_l0_stats);
+    if (m->h_fuse_fault) hipHostFree(m->h_fuse_fault);
   }
   delete m;
 }
@@ -1144,6 +1198,14 @@ int fdnn_debug_set_l0_list_cap(fdnn_model *m, int cap) {
 int fdnn_debug_set_pp(int mode, int min_frames) {
   if (mode < -1 || mode > 1) return fail(FDNN_E_ARG, "pp mode must be -1, 0 or 1");
   fdnn::qpp_set_mode(mode, min_frames);
+  return FDNN_OK;
+}
+
+int fdnn_debug_raise_fuse_fault(fdnn_model *m, int value) {
+  if (!m) return fail(FDNN_E_ARG, "null model");
+  if (!m->h_fuse_fault) return fail(FDNN_E_STATE, "this model has no fault word");
+  __atomic_store_n(m->h_fuse_fault, value ? 1ull : 0ull, __ATOMIC_RELAXED);
+  if (!value) m->fuse_fault_said = false;
   return FDNN_OK;
 }
 
@@ -1408,7 +1470,7 @@ int fdnn_calculate_device(fdnn_model *m, const float *d_x, int n, float *d_out, 
   DeviceGuard g(m->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   fdnn_ctx *c = nullptr;
-  const auto chunks = fdnn::frame_chunks(n);
+  const auto chunks = fdnn::frame_chunks(n, m);
   int cap = 0;  // the scratch only has to hold the largest chunk
   for (const auto &ch : chunks) cap = std::max(cap, ch.second);
   int rc = acquire_ctx(m, cap, &c);
@@ -1492,7 +1554,7 @@ int fdnn_calculate_lazy_bits_device(fdnn_model *m, const float *d_x, int n, cons
   DeviceGuard g(m->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   fdnn_ctx *c = nullptr;
-  const auto chunks = fdnn::frame_chunks(n);
+  const auto chunks = fdnn::frame_chunks(n, m);
   int cap = 0;
   for (const auto &ch : chunks) cap = std::max(cap, ch.second);
   int rc = acquire_ctx(m, cap, &c);
@@ -1561,9 +1623,11 @@ int fdnn_debug_forward_taps(fdnn_model *m, const float *x, int n, const int8_t *
   return FDNN_OK;
 }
 
-int fdnn_debug_frame_chunks(int n, int *chunks, int cap) {
+int fdnn_debug_frame_chunks(int n, int *chunks, int cap) { return fdnn_debug_frame_chunks_for(n, 1, chunks, cap); }
+
+int fdnn_debug_frame_chunks_for(int n, int chained, int *chunks, int cap) {
   if (n <= 0 || !chunks || cap <= 0) return -1;
-  const auto v = fdnn::frame_chunks(n);
+  const auto v = fdnn::frame_chunks(n, nullptr, chained != 0);
   if (static_cast<int>(v.size()) > cap) return -1;
   for (size_t i = 0; i < v.size(); ++i) {
     chunks[2 * i] = v[i].first;

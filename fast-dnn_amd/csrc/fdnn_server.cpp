@@ -93,6 +93,7 @@ struct Slot {
   bool rows_on_host = false;      // current batch: its rows have been brought to h_out
   int8_t *h_mask = nullptr;
   uint64_t *h_bits = nullptr;     // bit-mask batches: the batch's words (pinned; first such batch allocates)
+  bool h_bits_pageable = false;   // ... from malloc: pinned memory was refused
   float *d_comp = nullptr;        // ... its compacted result rows [rows][stride]
   float *h_comp = nullptr;        // ... and where they land on the host (pinned): ONE transfer per batch, behind the compaction
   size_t comp_floats = 0;
@@ -179,7 +180,7 @@ int enqueue_batch(fdnn_server *s, Slot &sl, const float *d_x, int n, const int8_
     const char *e = FDNN_TUNE_ENV("FDNN_SERVER_OVERLAP");
     return e ? std::atoi(e) != 0 : false;
   }();
-  const std::vector<std::pair<int, int>> chunks = small ? std::vector<std::pair<int, int>>{} : fdnn::frame_chunks(n);
+  const std::vector<std::pair<int, int>> chunks = small ? std::vector<std::pair<int, int>>{} : fdnn::frame_chunks(n, c->m);
   bool all_fused = !small;
   for (const auto &ch : chunks) all_fused = all_fused && (d_bits || fdnn::output_will_fuse(c, ch.second, d_masks));  // (a short tail chunk may take the unfused kernels)
   c->l0_chain_only = !small && overlap && !all_fused;  // see fdnn_ctx: an overlapped scale pass needs room beside layer 0
@@ -417,12 +418,35 @@ void packer_loop(fdnn_server *s) {
       e = hipSuccess;  // (no pinned memory to be had: the per-caller copies as before)
     }
     if (kind == kBits) {  // staging of the first bit-mask batch of this slot
-      if (!sl.h_bits) e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_bits), sizeof(uint64_t) * size_t(s->max_frames) * wpr, hipHostMallocDefault);
+      if (!sl.h_bits) {
+        const size_t bytes = sizeof(uint64_t) * size_t(s->max_frames) * wpr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&sl.h_bits), bytes, hipHostMallocDefault) != hipSuccess) {
+          // (advisor, round 5) no pinned memory to be had: pageable staging -- the copy to the device is then a synchronous
+          // one, the batch is not lost
+          (void)hipGetLastError();
+          sl.h_bits = static_cast<uint64_t *>(std::malloc(bytes));
+          sl.h_bits_pageable = sl.h_bits != nullptr;
+          if (!sl.h_bits) e = hipErrorOutOfMemory;
+        }
+      }
       const size_t need = size_t(s->max_frames) * (O * 3 / 4 + 1);
       if (e == hipSuccess && sl.stride > 0 && sl.comp_floats < need) {
-        e = hipMalloc(reinterpret_cast<void **>(&sl.d_comp), sizeof(float) * need);
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&sl.h_comp), sizeof(float) * need, hipHostMallocDefault);
-        if (e == hipSuccess) sl.comp_floats = need;
+        // both halves or neither: a device buffer without its pinned landing place was leaked by the next batch's attempt,
+        // and a failure here is not the batch's -- its rows go back uncompacted (per-caller copies)
+        float *d_new = nullptr, *h_new = nullptr;
+        hipError_t ec = hipMalloc(reinterpret_cast<void **>(&d_new), sizeof(float) * need);
+        if (ec == hipSuccess) ec = hipHostMalloc(reinterpret_cast<void **>(&h_new), sizeof(float) * need, hipHostMallocDefault);
+        if (ec == hipSuccess) {
+          if (sl.d_comp) hipFree(sl.d_comp);
+          if (sl.h_comp) hipHostFree(sl.h_comp);
+          sl.d_comp = d_new;
+          sl.h_comp = h_new;
+          sl.comp_floats = need;
+        } else {
+          (void)hipGetLastError();
+          if (d_new) hipFree(d_new);
+          sl.stride = 0;
+        }
       }
     }
     if (e == hipSuccess) {  // the pieces' copies: this thread and whoever is blocked in fdnn_server_wait, piece by piece
@@ -631,7 +655,8 @@ void fdnn_server_free(fdnn_server *s) {
     if (sl.ctx) fdnn::destroy_ctx(sl.ctx);
     if (sl.h_x) hipHostFree(sl.h_x);
     if (sl.h_mask) hipHostFree(sl.h_mask);
-    if (sl.h_bits) hipHostFree(sl.h_bits);
+    if (sl.h_bits && sl.h_bits_pageable) std::free(sl.h_bits);
+    else if (sl.h_bits) hipHostFree(sl.h_bits);
     if (sl.d_comp) hipFree(sl.d_comp);
     if (sl.h_comp) hipHostFree(sl.h_comp);
     if (sl.h_out) hipHostFree(sl.h_out);

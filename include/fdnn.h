@@ -269,6 +269,10 @@ FDNN_API int fdnn_debug_production_acc_out(fdnn_model *m, const float *x, int n,
  * reference blocks a call by `batch` frames (dnn.cc:402-454: blocking never changes a result); here a very large batch
  * runs as device-sized chunks for cache locality, results unchanged (tests / diagnostics). */
 FDNN_API int fdnn_debug_frame_chunks(int n, int *chunks, int cap);
+/* The same for a batch whose hidden layers run (chained != 0) or do not run as one chained launch: without the chain a few
+ * frames past a whole round of workgroups (up to 2 048) go as a batch of their own (host logic; fdnn_debug_set_chain(0),
+ * FDNN_CHAIN=0, fewer than two int8 hidden layers, a layer without the validated division are such configurations). */
+FDNN_API int fdnn_debug_frame_chunks_for(int n, int chained, int *chunks, int cap);
 
 /* Which kernel computes the canonical fp32 input layer (tests / measurements only; results are
  * bit-identical): 0 = by batch size (default), 1 = always the chain-pass kernel (128 x 128
@@ -313,6 +317,11 @@ FDNN_API int fdnn_debug_set_pp(int mode, int min_frames);
  * default (FDNN_PPO in the environment, else by batch size).  Process-wide; identical bits either way.
  * CalculateOutput + SoftMax::apply, src/cpp/dnn.cc:428-454, :534-544, is what is being computed. */
 FDNN_API int fdnn_debug_set_ppo(int mode);
+
+/* Tests: write the word a fused soft-max workgroup raises (in host memory) when it gives up waiting for its frame tile's
+ * siblings -- 1: as if a launch of this model had just done so (from the next call on the model runs the unfused soft-max
+ * and says so once on stderr), 0: forget it.  The production path needs no call: fdnn_gemm.hip / fdnn_ppo.hip raise it. */
+FDNN_API int fdnn_debug_raise_fuse_fault(fdnn_model *m, int value);
 
 /* Measurement builds of the chained hidden-layer kernel (-DFDNN_CHAIN_CLK=1; the shipped library records nothing): with
  * out == NULL, give the context a buffer for the phase clocks of cap_tasks tasks; with out != NULL copy the records of the

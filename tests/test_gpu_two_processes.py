@@ -47,7 +47,9 @@ def test_second_process_on_the_device_runs_unfused_by_itself(net_model_path):
 
     env = {k: v for k, v in os.environ.items() if k != "FDNN_FUSE_NORM"}
     dnn = api.QuantizedDnn.loadFromFile(net_model_path)  # this process owns (or already owned) the marker
-    assert not api.device_shared(0)
+    if api.device_shared(0):  # (advisor, round 5) machine state, not a defect: a leftover or parallel scorer holds the marker
+        dnn.delete()
+        pytest.skip("another process already holds the advisory marker of GPU 0: this test needs to be the first scorer on it")
     n = 10000
     x = torch.from_numpy(F.synth_features(n, 432, seed=41)).cuda()
     out = torch.empty((n, 8000), dtype=torch.float32, device="cuda")
@@ -55,6 +57,13 @@ def test_second_process_on_the_device_runs_unfused_by_itself(net_model_path):
     dnn.calculate_device(x.data_ptr(), n, out.data_ptr(), s)
     torch.cuda.synchronize()
     want = hashlib.sha256(out[:256].cpu().numpy().tobytes()).hexdigest()
+    alone = []  # this box's single-process pass, the yardstick of the bounds below
+    for _ in range(9):
+        t0 = time.perf_counter()
+        dnn.calculate_device(x.data_ptr(), n, out.data_ptr(), s)
+        torch.cuda.synchronize()
+        alone.append(time.perf_counter() - t0)
+    base = sorted(alone)[len(alone) // 2]
     child = subprocess.Popen([sys.executable, "-c", CHILD, ROOT, net_model_path], stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                              text=True, env=env)
     line = child.stdout.readline()
@@ -78,6 +87,47 @@ def test_second_process_on_the_device_runs_unfused_by_itself(net_model_path):
     for t in (times, res["times"]):
         t = sorted(t)
         # no cliff: the second slowest of the 20 within 3 x the median (one host hiccup is not a cliff), and the median itself
-        # nowhere near the tens of milliseconds a sat-out wait costs
-        assert t[-2] < 3.0 * t[len(t) // 2] + 2e-3 and t[len(t) // 2] < 20e-3, t
+        # a small multiple of this box's pass alone (two processes take turns on the device) -- a sat-out wait is tens of
+        # milliseconds, i.e. tens of passes.  (Bounds relative to the run's own baseline: advisor, round 5.)
+        assert t[-2] < 3.0 * t[len(t) // 2] + 4.0 * base and t[len(t) // 2] < 12.0 * base, (base, t)
+    dnn.delete()
+
+
+def test_a_give_up_flips_the_model_to_the_scale_pass_for_good(net_model_path, capfd):
+    """the device side of the detection.  A fused soft-max workgroup that sits out its bounded wait
+    raises a word in host memory (fdnn_gemm.hip / fdnn_ppo.hip); from the next call on the model runs GEMM + scale pass --
+    the same bits -- and says so once.  The word is written here as the kernel would (fdnn_debug_raise_fuse_fault)."""
+    import torch
+
+    if os.environ.get("FDNN_FUSE_NORM"):
+        pytest.skip("FDNN_FUSE_NORM forces the path")
+    dnn = api.QuantizedDnn.loadFromFile(net_model_path)
+    if api.device_shared(0):
+        dnn.delete()
+        pytest.skip("another process holds the advisory marker of GPU 0: this process does not fuse to begin with")
+    n = 4096
+    x = torch.from_numpy(F.synth_features(n, 432, seed=43)).cuda()
+    out = torch.empty((n, 8000), dtype=torch.float32, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+
+    def one_pass():
+        dnn.profileBegin()
+        dnn.calculate_device(x.data_ptr(), n, out.data_ptr(), s)
+        torch.cuda.synchronize()
+        prof = dnn.profileEnd()
+        return out.cpu().numpy().copy(), {k for k, v in prof.items() if v["launches"]}
+
+    fused_rows, fused_classes = one_pass()
+    assert "normalize" not in fused_classes
+    capfd.readouterr()
+    dnn.raiseFuseFault(1)
+    a, ca = one_pass()
+    b, cb = one_pass()
+    err = capfd.readouterr().err
+    assert "normalize" in ca and "normalize" in cb
+    assert err.count("sat out its bounded wait") == 1
+    assert np.array_equal(a.view(np.uint32), fused_rows.view(np.uint32)) and np.array_equal(b.view(np.uint32), fused_rows.view(np.uint32))
+    dnn.raiseFuseFault(0)
+    c, cc = one_pass()
+    assert "normalize" not in cc and np.array_equal(c.view(np.uint32), fused_rows.view(np.uint32))
     dnn.delete()

@@ -122,6 +122,12 @@ def test_very_large_batches_are_cut_into_whole_rounds():
     assert api.frame_chunks(15000) == [(0, 15000)]
     assert api.frame_chunks(33000) == [(0, 20480), (20480, 12520)]
     assert api.frame_chunks(31000) == [(0, 20480), (20480, 10520)]
+    # hidden layers launched layer by layer (chaining off / not possible): up to 2 048 frames past a whole round go alone
+    assert api.frame_chunks(11000, chained=False) == [(0, 10240), (10240, 760)]
+    assert api.frame_chunks(10240, chained=False) == [(0, 10240)]
+    assert api.frame_chunks(9000, chained=False) == [(0, 9000)]
+    assert api.frame_chunks(15000, chained=False) == [(0, 15000)]  # 4 760 past the round: worth its own round
+    assert api.frame_chunks(31000, chained=False) == [(0, 20480), (20480, 10240), (30720, 280)]
 
 
 def test_no_cpu_fallback_without_a_gpu(tiny_model_path):
