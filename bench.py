@@ -789,7 +789,20 @@ def main() -> None:
                 import csv
 
                 rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f"r06_small_{nn_}_kernel_stats.csv"))))
-                ks = {r_["Name"].split("fdnn::")[-1].split("(")[0][:60]: round(float(r_["AverageNs"]) / 1e3, 2) for r_ in rows if "fdnn" in r_["Name"] and int(r_["Calls"]) >= 100}
+                def _short(k):  # kernel name without namespaces and without its argument list (the first '(' outside template brackets)
+                    k = k.replace("void ", "").replace("fdnn::(anonymous namespace)::", "").replace("fdnn::", "")
+                    depth, out_ = 0, []
+                    for ch in k:
+                        if ch == "<":
+                            depth += 1
+                        elif ch == ">":
+                            depth -= 1
+                        elif ch == "(" and depth == 0:
+                            break
+                        out_.append(ch)
+                    return "".join(out_).strip()[:80]
+
+                ks = {_short(r_["Name"]): round(float(r_["AverageNs"]) / 1e3, 2) for r_ in rows if "fdnn" in r_["Name"] and int(r_["Calls"]) >= 100}
                 rs[f"kernel_avg_us_{nn_}_frames_replayed"] = ks
                 rs["replayed_from"] = "profiles/r06_small_*_kernel_stats.csv"
             except Exception:  # noqa: BLE001

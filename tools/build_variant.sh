@@ -14,6 +14,6 @@ FLAGS="-DFDNN_ABLATION -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=of
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS -c fdnn_small.hip -o $V/fdnn_small.o &
 /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS -c fdnn_l0s.hip -o $V/fdnn_l0s.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libfast-dnn-$NAME.so $V/fdnn_gemm.o $V/fdnn_l0.o $V/fdnn_kernels.o $V/fdnn_small.o $V/fdnn_l0s.o $OUT/fdnn_chain.o \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libfast-dnn-$NAME.so $V/fdnn_gemm.o $V/fdnn_l0.o $V/fdnn_kernels.o $V/fdnn_small.o $V/fdnn_l0s.o $OUT/fdnn_chain.o $OUT/fdnn_pp.o $OUT/fdnn_ppo.o \
   $OUT/fdnn_runtime.o $OUT/fdnn_server.o $OUT/fdnn_group.o $OUT/fdnn_model.o $OUT/fdnn_jni.o -ldl -lpthread
 echo "$OUT/libfast-dnn-$NAME.so"
