@@ -117,6 +117,48 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float *out, float 
   normalize_row<(FDNN_NORM_NT != 0)>(out, dst, partial, blockIdx.x, partial_ld, rows, n_partial, red);
 }
 
+// The pass for SMALL batches (one utterance: 100 rows on 256 CUs, latency bound): the row's e_i are requested first -- eight
+// 16-byte loads per thread, nothing they depend on -- and the total is formed meanwhile by ONE wave from registers (the S_j in
+// lanes, the tree's levels by lane permutes: the same additions in the same order as normalize_row, no barrier per level);
+// one barrier, scale, store.  Three dependent round trips and eleven barriers become two and one: 6.2 -> see LABBOOK (100 rows).
+// Rows of whole 16-byte groups, at most 8 192 wide, at most 64 tiles of 256 nodes; anything else takes normalize_kernel.
+__global__ __launch_bounds__(256) void normalize_small_kernel(const float *out, float *dst, const float *partial, int n, int partial_ld,
+                                                              int rows, int n_partial) {
+  __shared__ float tot_s;
+  const int tid = threadIdx.x, f = blockIdx.x;
+  const float4 *r4 = reinterpret_cast<const float4 *>(out + static_cast<size_t>(f) * rows);
+  float4 *d4 = reinterpret_cast<float4 *>(dst + static_cast<size_t>(f) * rows);
+  const int groups = rows >> 2;
+  float4 v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = tid + 256 * q;
+    v[q] = i < groups ? r4[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  if (tid < 64) {
+    const int MT = n_partial >> 2;
+    int L = 1;
+    while (L < MT) L <<= 1;
+    float sj = 0.0f;
+    if (tid < MT) {
+      const float *pp = partial + static_cast<size_t>(4 * tid) * partial_ld + f;
+      sj = (pp[0] + pp[partial_ld]) + (pp[2 * static_cast<size_t>(partial_ld)] + pp[3 * static_cast<size_t>(partial_ld)]);
+    }
+    for (int len = L >> 1; len >= 1; len >>= 1) {  // level by level, adjacent pairs: lane t < len takes values 2t, 2t + 1 of the level before
+      const float a = __shfl(sj, (2 * tid) & 63), b = __shfl(sj, (2 * tid + 1) & 63);
+      sj = a + b;
+    }
+    if (tid == 0) tot_s = sj;
+  }
+  __syncthreads();
+  const float inv = 1.0f / tot_s;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = tid + 256 * q;
+    if (i < groups) d4[i] = make_float4(v[q].x * inv, v[q].y * inv, v[q].z * inv, v[q].w * inv);
+  }
+}
+
 // The same pass as a BACKGROUND kernel for the server loop: a fixed, small grid of workgroups that
 // walk the rows, so that it holds one or two wave slots per SIMD for its whole life instead of
 // flooding every CU with thousands of short workgroups.  Launched on the low-priority tail stream
@@ -301,6 +343,12 @@ void launch_normalize(float *out, float *dst, const float *partial, int n, int p
       return e ? std::max(1, std::atoi(e)) : 256;  // sweep, 2 steps in flight: 192-256 best (+7-8 % over one stream), 512 +4 %, 1024 +2 %
     }();
     hipLaunchKernelGGL(normalize_bg_kernel, dim3(std::min(n, wgs)), dim3(256), 0, s, out, dst, partial, n, partial_ld, rows, n_partial);
+    return;
+  }
+  const bool small_ok = n <= 1024 && (rows & 3) == 0 && rows <= 8192 && (n_partial >> 2) <= 64 &&
+                        ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  if (small_ok) {
+    hipLaunchKernelGGL(normalize_small_kernel, dim3(n), dim3(256), 0, s, out, dst, partial, n, partial_ld, rows, n_partial);
     return;
   }
   hipLaunchKernelGGL(normalize_kernel, dim3(n), dim3(256), 0, s, out, dst, partial, n, partial_ld, rows, n_partial);

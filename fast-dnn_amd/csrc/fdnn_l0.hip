@@ -1136,14 +1136,22 @@ __global__ __launch_bounds__(THREADS) void l0_fix_list_kernel(L0Params p, int ti
   float *tr_w = fix_smem + 2 * p.D + (tid >> 6) * (NB * 256);  // this wave's product blocks (fix_one_output)
   const uint32_t total = min(p.glist_count[0], static_cast<uint32_t>(p.glist_cap));
   const bool any_overflow = p.glist_count[1] != 0u;  // some tile kept its outputs to itself (scr_count / whole-tile path)
-  if (static_cast<uint32_t>(blockIdx.x) * (kFixThreads / LPO) >= total && !any_overflow) return;
+  // Which piece of the list is whose: the list is (nearly) in tile order, frame tiles major, so a contiguous eighth of it
+  // touches an eighth of the frame rows -- and workgroup b runs on XCD b % 8, whose L2 is its own.  Workgroup b takes piece
+  // (b % 8) * pieces_per_xcd + b / 8 (+ gridDim / 8, ...): an XCD's L2 then holds ITS frame rows beside the weight rows
+  // (2.1 + 3.5 MB on the bench batch) instead of every XCD streaming all 17 MB of rows through 4 MB (FDNN_L0_FIX_XCD=0: b -> piece b).
+  const uint32_t per = kFixThreads / LPO, pieces = (total + per - 1) / per, ppx = (pieces + 7) / 8;
+  const uint32_t xcd = blockIdx.x & 7u, wj = blockIdx.x >> 3, wpx = max(1u, gridDim.x >> 3);
+  if (wj >= ppx && !any_overflow) return;
   for (int k = tid; k < p.D; k += kFixThreads) {
     sh_s[k] = p.shift[k];
     sc_s[k] = p.scale[k];
   }
   __syncthreads();
-  for (uint32_t base = blockIdx.x * (kFixThreads / LPO); base < total; base += gridDim.x * (kFixThreads / LPO)) {
-    const uint32_t o = base + (tid / LPO);
+  for (uint32_t pj = wj; pj < ppx; pj += wpx) {
+    const uint32_t piece = xcd * ppx + pj;
+    if (piece >= pieces) break;
+    const uint32_t o = piece * per + (tid / LPO);
     const bool valid = o < total;
     const uint2 ent = valid ? p.glist[o] : make_uint2(0u, 0u);
     fix_one_output<NB, LPO>(p, sh_s, sc_s, tr_w, static_cast<int>(ent.x), static_cast<int>(ent.y), valid && ent.x < static_cast<uint32_t>(p.n) && ent.y < static_cast<uint32_t>(p.H), c, quads);
@@ -1296,7 +1304,7 @@ void launch_l0(const L0Params &p, hipStream_t s) {
     const int lpo = force_lpo ? (force_lpo == 8 ? 8 : 4) : (p.n_rows < 3000 ? 8 : 4);
     // enough workgroups for 1.5 % flagged in one pass each (0.35 % on the bench batch); more is walked in further passes
     const long expect = static_cast<long>(p.n_rows) * p.H * 3 / 200 / (thr / lpo) + 8;
-    const int grid = static_cast<int>(std::min<long>(expect, 8192));
+    const int grid = static_cast<int>(std::min<long>((expect + 7) / 8 * 8, 8192));  // (a multiple of 8: l0_fix_list_kernel deals its pieces per XCD)
     const int tiles = node_tiles * frame_tiles;
 #define FDNN_FIX_LAUNCH(NB_, T_, L_) hipLaunchKernelGGL((l0_fix_list_kernel<NB_, T_, L_>), dim3(grid), dim3(T_), 2 * sizeof(float) * p.D + (T_ / 64) * NB_ * 1024, s, p, tiles)
 #define FDNN_FIX_LAUNCH_T(T_)                                                        \
