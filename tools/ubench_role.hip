@@ -123,8 +123,18 @@ __global__ __launch_bounds__(512, 2) void role_kernel(P p) {
       // ------------------------------------------------ compute role: fragment reads and MFMAs only
       if (FLAGS & 32) __builtin_amdgcn_s_setprio(1);
       load_frags(ph * 16, 0, 0);
+      const auto ra_c = rsrc_a_of(ph), ra_cn = rsrc_a_of(ph + 1);
+      const auto rw_c = rsrc_w_of(ph);
       for (int kt = 0; kt < 16; ++kt) {
         const int T = ph * 16 + kt;
+        if ((FLAGS & 512) && T + 1 < T_end) {  // the COMPUTE wave requests its own next activation rows (5 of the tick's 13 pieces)
+#pragma unroll
+          for (int i = 0; i < 5; ++i) {
+            if (kt == 15) stage_load(rw_c, ra_cn, 0, 0, 8 + i);
+            else stage_load(rw_c, ra_c, kt + 1, 0, 8 + i);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int kk = 0; kk < 3; ++kk) {
           if (FLAGS & 128) __builtin_amdgcn_sched_barrier(0);
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(512, 2) void role_kernel(P p) {
           }
         }
         if (FLAGS & 384) __builtin_amdgcn_sched_barrier(0);
+        if (FLAGS & 512) __builtin_amdgcn_s_waitcnt(0x0f70);  // my rows of the next stage have landed
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this stage's fragments are all in registers
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void role_kernel(P p) {
         };
         if (!(FLAGS & 2)) {
 #pragma unroll
-          for (int i = 0; i < 13; ++i) piece(i);
+          for (int i = (FLAGS & 512) ? 5 : 0; i < 13; ++i) piece(i);
         }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -276,5 +287,9 @@ int main() {
   run<156, 321>("W3/A2, interleaved, V = 156, setprio around MFMA blocks", w, a, out);
   run<156, 352>("W3/A2, interleaved, V = 156, static setprio", w, a, out);
   run<156, 128>("2 stages, pinned, V = 156", w, a, out);
+  run<0, 832>("rows requested by the COMPUTE wave, W by the partner, V = 0", w, a, out);
+  run<104, 832>("rows requested by the COMPUTE wave, V = 104", w, a, out);
+  run<156, 832>("rows requested by the COMPUTE wave, V = 156", w, a, out);
+  run<208, 832>("rows requested by the COMPUTE wave, V = 208", w, a, out);
   return 0;
 }
