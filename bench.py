@@ -677,6 +677,32 @@ def main() -> None:
                      "vs_headline_net_single_stream": round((single_elapsed / args.steps) / (en / args.steps), 4),
                      "note": "same 432 -> 7x2048 -> 8000 topology and seed, weights quantised so that no adjacent pair can leave int16 "
                              "(|w_q| <= 64): the layers run the instances without the pair-saturation walk"}
+            # ... and, on this net, the round-6 role-split fused output kernel (fdnn_ppo.hip; selectable, bit-identical, not the
+            # default): the same pass with it switched on, per-class device time of the output layer from the profiling scopes
+            try:
+                def _out_us(ppo_mode):
+                    api.set_ppo(ppo_mode)
+                    for _ in range(5):
+                        dn.calculate_device(x.data_ptr(), n, outs[0].data_ptr(), stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    dn.profileBegin()
+                    t_ = time.perf_counter()
+                    for _ in range(20):
+                        dn.calculate_device(x.data_ptr(), n, outs[0].data_ptr(), stream.cuda_stream)
+                    torch.cuda.synchronize()
+                    e_ = time.perf_counter() - t_
+                    pr_ = dn.profileEnd()
+                    return round(pr_["output_gemm"]["ms"] / 20 * 1e3, 1), round(e_ / 20 * 1e3, 4)
+
+                in_phase = _out_us(0)
+                split = _out_us(1)
+                nosat["role_split_output_kernel"] = {"output_layer_us": split[0], "in_phase_output_layer_us": in_phase[0], "ms_per_step": split[1],
+                                                     "in_phase_ms_per_step": in_phase[1], "give_ups": int(dn.fuseGiveups()),
+                                                     "note": "fdnn_debug_set_ppo(1) vs (0), 20 passes each under the library's profiling scopes (which add a few us per pass)"}
+            except Exception as e2_:  # noqa: BLE001
+                nosat["role_split_output_kernel"] = {"error": str(e2_)[:200]}
+            finally:
+                api.set_ppo(-1)
             dn.delete()
         except Exception as e_:  # noqa: BLE001
             nosat = {"error": str(e_)[:200]}
