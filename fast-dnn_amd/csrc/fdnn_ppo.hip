@@ -45,7 +45,11 @@ namespace {
 [[maybe_unused]] constexpr int kNF = 5, kBK = 128, kBM = 256, kHT = 32 * kNF, kFT = 2 * kHT, kKT = 16, kTS = kBM + 16;
 [[maybe_unused]] constexpr int kWStages = 3;
 [[maybe_unused]] constexpr int kMT = 32;       // node tiles of the layer (rows_pad = 8192): the 32 x 160 sums of a half are one 20 KB block
-[[maybe_unused]] constexpr int kPub = 10;      // tick after whose barrier a half's sums are published
+#ifndef FDNN_PPO_EXP_PER
+#define FDNN_PPO_EXP_PER 6  // epilogue items (of four outputs per lane) per tick (4: 225 us, 5: 255, 6 .. 8: 213 .. 219, 10: 247 -- pair-free net, 10 000 frames)
+#endif
+[[maybe_unused]] constexpr int kExpPer = FDNN_PPO_EXP_PER;
+[[maybe_unused]] constexpr int kPub = (8 * kNF + kExpPer - 1) / kExpPer;  // tick after whose barrier a half's sums are published: the first without exp items
 [[maybe_unused]] constexpr int kExtBound = 1 << 14;  // extension ticks before a workgroup stops waiting for its siblings (tens of milliseconds)
 
 // ---- the accumulators: in the ACCUMULATION registers a0 .. a159, behind the compiler's back.  A wave's ten 32 x 32 tiles
@@ -600,9 +604,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
           }
 #endif
           __builtin_amdgcn_sched_barrier(0);
-          if (evalid && kt < kPub) {  // my epilogue's arithmetic: four items (one accumulator tile) a tick
+          if (evalid && kt < kPub) {  // my epilogue's arithmetic: kExpPer items a tick (four = one accumulator tile)
 #pragma unroll
-            for (int it = 4 * kt; it < 4 * kt + 4; ++it) {
+            for (int it = kExpPer * kt; it < kExpPer * kt + kExpPer && it < 8 * kNF; ++it) {
               exp_item(it);
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -637,32 +641,47 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
           if (all_scaled || ++ext_iters > kExtBound) break;
           if (inv_ready && !scaled) {
 #if !(FDNN_PPO_DEBUG & 32)
-            // one descriptor for the pair's rows that exist (frames past n fall outside it), one lane offset for all 40
-            // stores: the frame block comes as the scalar offset, the item as the immediate; nodes past the layer's last
-            // (the last node tile only) get an offset outside everything
+            // The outputs leave as WHOLE ROW SEGMENTS.  Straight from the accumulators' layout a store instruction is 32 frames
+            // x 32 bytes -- 32 different cache lines, a quarter each: 160 such instructions per workgroup and half took 12 000
+            // cycles (46 of the kernel's 225 us: measured by leaving them out).  Instead a frame block (32 frames x the wave's 64
+            // nodes) is scaled into a park -- row stride 272 bytes -- in the LDS the rings do not need right now (the weight
+            // buffer and the row buffer read in tick 15: the next phase's first requests for them come after this tick's last
+            // barrier), read back as rows, and every store instruction writes four rows x 256 contiguous bytes.
+            // One descriptor for the pair's rows that exist (frames past n fall outside it), one lane offset for all 40 stores,
+            // the frames as the scalar offset; nodes past the layer's last (the last node tile only): an offset outside everything.
             typedef unsigned int v4u __attribute__((ext_vector_type(4)));
             const int f0 = e_pair * kFT;
             const int rows_s = p.rows;
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(p.final + static_cast<size_t>(f0) * rows_s, 0,
                                                                                   max(0, min(kFT, p.n - f0)) * rows_s * 4, 0x00020000);
-            const int node0 = my_mt * kBM + 64 * wm + 4 * (ln >> 5);
-            const int lim = rows_s - node0;  // this lane's item at node offset o exists iff o + 4 <= lim
-            const int voff = ((sg * kHT + (ln & 31)) * rows_s + node0) * 4;
-#pragma unroll
-            for (int it = 0; it < 8 * kNF; ++it) {
-              const int ni = it >> 3, mi = (it >> 2) & 1, g = it & 3;
+            const int t_last = gt0 + kKT - 1;  // the tick whose buffers are free now
+            char *park = wm < 3 ? &ringW[t_last % kWStages][wm * (32 * kTS)] : &ringA[t_last & 1][0];
+            char *park_w = park + (ln & 31) * kTS + (ln >> 5) * 16;            // my frame's row, my half's 16 bytes of every 32
+            const char *park_r = park + (ln >> 4) * kTS + (ln & 15) * 16;      // rows 4 j + lane / 16, 16 bytes at (lane % 16) x 16
+            const int node_r = my_mt * kBM + 64 * wm + 4 * (ln & 15);
+            const int voff = node_r + 4 <= rows_s ? ((sg * kHT + (ln >> 4)) * rows_s + node_r) * 4 : static_cast<int>(0x80000000u);
+#pragma clang loop unroll(full)
+            for (int ni = 0; ni < kNF; ++ni) {
               const float iv = inv_s[32 * ni + (ln & 31)];
-              v4f_t o4;
-              switch (it) {
+#pragma clang loop unroll(full)
+              for (int it = 8 * ni; it < 8 * ni + 8; ++it) {
+                const int mi = (it >> 2) & 1, g = it & 3;
+                v4f_t o4;
+                switch (it) {
 #define X(IT, OFF, R0, R1, R2, R3) \
   case IT: PPO_SCL4(R0, R1, R2, R3); break;
-                PPO_ITEMS(X)
+                  PPO_ITEMS(X)
 #undef X
-                default: break;
+                  default: break;
+                }
+                *reinterpret_cast<v4f_t *>(park_w + (32 * mi + 8 * g) * 4) = o4;
               }
 #if !(FDNN_PPO_DEBUG & 8)
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, o4), ro, 32 * mi + 8 * g + 4 <= lim ? voff : static_cast<int>(0x80000000u),
-                                                     32 * ni * rows_s * 4 + (32 * mi + 8 * g) * 4, 0);
+#pragma clang loop unroll(full)
+              for (int j = 0; j < 8; ++j) {
+                const v4u v = *reinterpret_cast<const v4u *>(park_r + 4 * j * kTS);
+                __builtin_amdgcn_raw_buffer_store_b128(v, ro, voff, (32 * ni + 4 * j) * rows_s * 4, 0);
+              }
 #endif
               __builtin_amdgcn_sched_barrier(0);
             }
@@ -710,9 +729,12 @@ bool qppo_ok(int rows, int rows_pad, int K, int n, bool fastdiv, bool has_fix) {
   const int forced = g_ppo_mode.load(std::memory_order_relaxed);
   const int mode = forced >= 0 ? forced : env_mode;
   if (mode == 0 || !fastdiv || K != kKT * kBK || rows_pad != kMT * kBM || (rows & 3) != 0) return false;
-  (void)has_fix;
-  (void)n;
-  return mode == 1;  // off unless asked for (FDNN_PPO=1 / fdnn_debug_set_ppo(1)): see the measurements in profiles/LABBOOK.md, round 6
+  if (mode == 1) return true;
+  // By default where it was measured ahead of the in-phase fused tiles on every box (tools/ppo_time.py, LABBOOK round 6):
+  // a layer without saturating pairs (trained nets) from 5 120 frames (two pairs per workgroup; 10 000 frames: 191 .. 219 us
+  // against 218 .. 227, 20 480: 391 against 444), a layer with pairs -- its walk runs in a lone compute wave -- from 12 000
+  // (10 000: at par, 8 000: 227 against 198).
+  return n >= (has_fix ? 12000 : 2 * kFT * 8);
 }
 
 int qppo_frame_tile() { return kFT; }
