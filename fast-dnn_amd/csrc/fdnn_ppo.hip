@@ -465,52 +465,63 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
         const int T = gt0 + kt;
         if (cvalid) {
           const char *at = ringA[T & 1];
-          while (!NOFIX && fix_k_next < (kt + 1) * kBK) {  // rare: a risky pair lives in this k-step (fdnn_gemm.hip's walk)
+          // The saturating-pair walk (fdnn_gemm.hip's): for every listed pair of this k-step a screen -- three 16-bit LDS reads,
+          // a dot product, a ballot -- and, where a frame fires, the exact correction.  A screen is a latency chain that two
+          // waves per SIMD hide from each other and a lone compute wave cannot: the FIRST due entry's reads are issued in
+          // front of sub-step 0 and looked at behind its ten MFMAs (an int32 correction may come at any point of the phase).
+          auto screen_read = [&](int j) {
+            const int kl = static_cast<int>(fix_raw & 0xffff) - kt * kBK;
+            const int row = 64 * j + ln;
+            const int rr_ = row < kHT ? row : 0;
+            return static_cast<int>(*reinterpret_cast<const uint16_t *>(at + rr_ * kBK + (((kl >> 4) ^ swz<kBK>(rr_)) << 4) + (kl & 15)));
+          };
+          auto walk_one = [&](int v0, int v1, int v2) {
             const int node = static_cast<int>(fix_raw >> 32) - fix_node0;
             const int kl = static_cast<int>(fix_raw & 0xffff) - kt * kBK;
             const int w0 = static_cast<int8_t>(fix_raw >> 16), w1 = static_cast<int8_t>(fix_raw >> 24);
-            {
-              const int wpk = (w0 & 0xff) | ((w1 & 0xff) << 8);
-              const int pbase = 128 * (w0 + w1) + 32768;
-              bool fire = false;
+            const int wpk = (w0 & 0xff) | ((w1 & 0xff) << 8);
+            const int pbase = 128 * (w0 + w1) + 32768;
+            const int vs[3] = {v0, v1, v2};
+            bool fire = false;
 #pragma unroll
-              for (int j = 0; j < (kNF + 1) / 2; ++j) {
-                const int row = 64 * j + ln;
-                const bool live = row < kHT;
-                const int rr_ = live ? row : 0;
-                const int v = *reinterpret_cast<const uint16_t *>(at + rr_ * kBK + (((kl >> 4) ^ swz<kBK>(rr_)) << 4) + (kl & 15));
-                const int ps = __builtin_amdgcn_sdot4(v, wpk, pbase, false);  // p + 32768
-                fire |= live && static_cast<unsigned>(ps) > 65535u;
-              }
-              if (__ballot(fire) == 0ull) {
-                ++fix_e;
-                fix_raw = fix_raw_nxt;
-                fix_k_next = fix_e < fix_end ? static_cast<int>(fix_raw & 0xffff) : INT_MAX;
-                if (fix_e + 1 < fix_end) fix_raw_nxt = ent_c[fix_e + 1];
-                continue;
-              }
+            for (int j = 0; j < (kNF + 1) / 2; ++j) {
+              const int ps = __builtin_amdgcn_sdot4(vs[j], wpk, pbase, false);  // p + 32768
+              fire |= 64 * j + ln < kHT && static_cast<unsigned>(ps) > 65535u;
             }
-            const int rr = node & 31;
-            const int idx = __builtin_amdgcn_readfirstlane((node >> 5) * 16 + (rr & 3) + 4 * (rr >> 3));  // mi * 16 + reg
-            const bool mine = (ln >> 5) == ((rr >> 2) & 1);
-            int c[kNF];
+            if (__ballot(fire) != 0ull) {
+              const int rr = node & 31;
+              const int idx = __builtin_amdgcn_readfirstlane((node >> 5) * 16 + (rr & 3) + 4 * (rr >> 3));  // mi * 16 + reg
+              const bool mine = (ln >> 5) == ((rr >> 2) & 1);
+              int c[kNF];
 #pragma unroll
-            for (int ni = 0; ni < kNF; ++ni) {
-              const int row = 32 * ni + frow;
-              const uint32_t pr = *reinterpret_cast<const uint16_t *>(at + row * kBK + (((kl >> 4) ^ swz<kBK>(row)) << 4) + (kl & 15));
-              const int a0 = static_cast<int>((pr & 0xff) ^ 0x80), a1 = static_cast<int>((pr >> 8) ^ 0x80);  // back to u8
-              const int prod = a0 * w0 + a1 * w1;
-              c[ni] = mine ? max(-32768, min(32767, prod)) - prod : 0;
+              for (int ni = 0; ni < kNF; ++ni) {
+                const int row = 32 * ni + frow;
+                const uint32_t pr = *reinterpret_cast<const uint16_t *>(at + row * kBK + (((kl >> 4) ^ swz<kBK>(row)) << 4) + (kl & 15));
+                const int a0 = static_cast<int>((pr & 0xff) ^ 0x80), a1 = static_cast<int>((pr >> 8) ^ 0x80);  // back to u8
+                const int prod = a0 * w0 + a1 * w1;
+                c[ni] = mine ? max(-32768, min(32767, prod)) - prod : 0;
+              }
+              ppo_add(idx, c);
             }
-            ppo_add(idx, c);
             ++fix_e;
             fix_raw = fix_raw_nxt;
             fix_k_next = fix_e < fix_end ? static_cast<int>(fix_raw & 0xffff) : INT_MAX;
             if (fix_e + 1 < fix_end) fix_raw_nxt = ent_c[fix_e + 1];
+          };
+          const bool due = !NOFIX && fix_k_next < (kt + 1) * kBK;
+          int sv0 = 0, sv1 = 0, sv2 = 0;
+          if (due) {
+            sv0 = screen_read(0);
+            sv1 = screen_read(1);
+            sv2 = screen_read(2);
           }
           __builtin_amdgcn_sched_barrier(0);
+          substep(true, true, T, 1, 1, 0);
+          if (due) walk_one(sv0, sv1, sv2);
+          while (!NOFIX && fix_k_next < (kt + 1) * kBK) walk_one(screen_read(0), screen_read(1), screen_read(2));  // (further entries of the k-step)
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int kk = 0; kk < 3; ++kk) substep(true, true, T, kk + 1, (kk + 1) & 1, kk & 1);
+          for (int kk = 1; kk < 3; ++kk) substep(true, true, T, kk + 1, (kk + 1) & 1, kk & 1);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this stage's fragments are all in registers
         __builtin_amdgcn_s_barrier();
@@ -730,11 +741,12 @@ bool qppo_ok(int rows, int rows_pad, int K, int n, bool fastdiv, bool has_fix) {
   const int mode = forced >= 0 ? forced : env_mode;
   if (mode == 0 || !fastdiv || K != kKT * kBK || rows_pad != kMT * kBM || (rows & 3) != 0) return false;
   if (mode == 1) return true;
-  // By default where it was measured ahead of the in-phase fused tiles on every box (tools/ppo_time.py, LABBOOK round 6):
-  // a layer without saturating pairs (trained nets) from 5 120 frames (two pairs per workgroup; 10 000 frames: 191 .. 219 us
-  // against 218 .. 227, 20 480: 391 against 444), a layer with pairs -- its walk runs in a lone compute wave -- from 12 000
-  // (10 000: at par, 8 000: 227 against 198).
-  return n >= (has_fix ? 12000 : 2 * kFT * 8);
+  // By default where it was measured ahead of the in-phase fused tiles (tools/ppo_time.py, several boxes; LABBOOK round 6):
+  // a layer without saturating pairs (trained nets) from 5 120 frames = two frame pairs per workgroup (10 000 frames: 191 ..
+  // 212 us against 218 .. 226, 20 480: 391 against 444, 5 120: 105 against 113); a layer with pairs -- the walk runs in a
+  // lone compute wave -- from 29 frame pairs (9 000 frames: 223 against 229, 10 000: 223 against 232, 12 000: 272 against
+  // 298, 16 000: 382 against 407; at 8 000 frames = 25 pairs on 8 slots it loses, 216 against 200).
+  return has_fix ? n > 28 * kFT : n >= 2 * kFT * 8;
 }
 
 int qppo_frame_tile() { return kFT; }

@@ -315,7 +315,7 @@ FDNN_API int fdnn_debug_set_pp(int mode, int min_frames);
  * exchange of the 256-node row sums and the scale run beside the next half's k-loop) whenever the shape allows (8 000-node
  * class layer: 32 node tiles, 2 048 inputs, dense, validated division), 0 = fdnn_gemm.hip's in-phase fused tiles, -1 = the
  * default (FDNN_PPO in the environment, else: a layer without saturating weight pairs from 5 120 frames, one with pairs from
- * 12 000).  Process-wide; identical bits either way.
+ * 8 961).  Process-wide; identical bits either way.
  * CalculateOutput + SoftMax::apply, src/cpp/dnn.cc:428-454, :534-544, is what is being computed. */
 FDNN_API int fdnn_debug_set_ppo(int mode);
 
