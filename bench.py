@@ -1061,10 +1061,16 @@ def main() -> None:
             add("hidden_gemm", "qgemm_kernel<hidden> (int8 MFMA 32x32x32, 2048x2048 layer + dequant/bias/sigmoid-table epilogue)",
                 "mfma", 2.0 * 2048 * 2048 * n, INT8_PEAK_TOPS, "TOP/s", 1e12, 2048 * 2048 + 2 * n * 2048, "qgemm_kernel hidden")
         fused_out = not prof["normalize"]["launches"]
-        add("output_gemm", "qgemm_kernel<output> (int8 MFMA, 8000x2048 layer + dequant/bias/exp epilogue" +
-            (" + FUSED soft-max: row sums exchanged between the 256-node tiles of a frame tile, probabilities written directly, "
-             "32 KB per frame out)" if fused_out else ", 32 KB of exp(z) per frame out)"),
-            "mfma", 2.0 * 2048 * O * n, INT8_PEAK_TOPS, "TOP/s", 1e12, 2048 * O + n * 2048 + 4 * n * O, "qgemm_kernel output")
+        ppo_out = fused_out and any(name.startswith("qppo_kernel") for name in pmc)  # (round 6: the role-split fused kernel is the default at this size when the committed profile shows it)
+        if ppo_out:
+            add("output_gemm", "qppo_kernel (int8 MFMA, 8000x2048 layer, two groups of four waves alternating k-loop / epilogue; FUSED soft-max: exp in place in the "
+                "accumulation registers, row sums exchanged between the 32 node tiles of a frame half, probabilities written as whole row segments, 32 KB per frame out)",
+                "mfma", 2.0 * 2048 * O * n, INT8_PEAK_TOPS, "TOP/s", 1e12, 2048 * O + n * 2048 + 4 * n * O, "qppo_kernel output")
+        else:
+            add("output_gemm", "qgemm_kernel<output> (int8 MFMA, 8000x2048 layer + dequant/bias/exp epilogue" +
+                (" + FUSED soft-max: row sums exchanged between the 256-node tiles of a frame tile, probabilities written directly, "
+                 "32 KB per frame out)" if fused_out else ", 32 KB of exp(z) per frame out)"),
+                "mfma", 2.0 * 2048 * O * n, INT8_PEAK_TOPS, "TOP/s", 1e12, 2048 * O + n * 2048 + 4 * n * O, "qgemm_kernel output")
         add("normalize", "normalize_kernel (soft-max scale: read + write [n][8000] fp32)", "hbm", 2.0 * O * 4 * n, HBM_PEAK_GBS,
             "GB/s", 1e9, 2 * O * 4 * n, "normalize_kernel")
         dominant = max(kinds, key=lambda k: k["ms_per_step"])

@@ -32,6 +32,8 @@ def label(kernel_name: str):
     if "qchain_kernel" in kernel_name:
         args = kernel_name.split("qchain_kernel<")[1].split(">")[0].replace(" ", "").split(",")
         return f"qchain_kernel (all hidden layers in one launch, 256x{32 * int(args[0]) * int(args[1])} tile, {4 * int(args[1])} waves, BK{args[2]})"
+    if "qppo_kernel" in kernel_name:
+        return "qppo_kernel output (role-split fused output layer, 256x160 halves, 8 waves, BK128)"
     if "qgemm_kernel" in kernel_name:
         args = kernel_name.split("qgemm_kernel<")[1].split(">")[0].replace(" ", "").split(",")
         kind = "output" if args[4] == "true" else "hidden"

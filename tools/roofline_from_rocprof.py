@@ -37,6 +37,10 @@ for r in rows:
         ent = dict(kernel=f"qchain_kernel (the {NL} hidden layers in one persistent launch) {32 * int(args[0]) * int(args[1])}-frame tile", bound="mfma",
                    achieved=round(NL * 2.0 * H * H * n / (avg_us * 1e-6) / 1e12, 1), peak=5000.0, unit="TOP/s",
                    algorithmic_bytes_per_launch=NL * (H * H + 2 * n * H), traffic=traffic("qchain_kernel"))
+    elif "qppo_kernel" in nm:
+        ent = dict(kernel="qppo_kernel (role-split output layer + fused soft-max, 256 x 160 halves)", bound="mfma",
+                   achieved=round(2.0 * O * H * n / (avg_us * 1e-6) / 1e12, 1), peak=5000.0, unit="TOP/s",
+                   algorithmic_bytes_per_launch=O * H + n * H + 4 * n * O, traffic=traffic("qppo_kernel output"))
     elif "qgemm_kernel" in nm:
         args = nm.split("qgemm_kernel<")[1].split(">")[0].replace(" ", "").split(",")
         output = args[4] == "true"
