@@ -101,6 +101,7 @@ struct fdnn_ctx {
   int8_t *d_mask = nullptr;       // [n][O]
   float *d_fuse_s = nullptr;        // fused soft-max: per-tile row sums [n_pad / tile][rows_pad / 256][tile] floats
   uint32_t *d_fuse_cnt = nullptr;   // {arrived part 0 .., left at [7]} per frame tile; zero between launches
+  size_t fuse_cnt_bytes = 0, fuse_flag_bytes = 0;
   uint32_t *d_fuse_flag = nullptr;  // per tile: parts a workgroup left unscaled ("gave up waiting"); zero between launches
   uint32_t *d_chain_ctl = nullptr;   // chained hidden layers (fdnn_chain.hip): queue heads [0..7], workgroups that left [8]
   uint32_t *d_chain_done = nullptr;  // [frame tiles][layers of the chain] node tiles finished; zero between launches

@@ -50,7 +50,7 @@ namespace {
 #endif
 [[maybe_unused]] constexpr int kExpPer = FDNN_PPO_EXP_PER;
 [[maybe_unused]] constexpr int kPub = (8 * kNF + kExpPer - 1) / kExpPer;  // tick after whose barrier a half's sums are published: the first without exp items
-[[maybe_unused]] constexpr int kExtBound = 1 << 14;  // extension ticks before a workgroup stops waiting for its siblings (tens of milliseconds)
+[[maybe_unused]] constexpr int kExtBound = 1 << 16;  // extension ticks (two barriers and a few LDS reads each: ~500 cycles) before a workgroup stops waiting for its siblings: ~15 ms -- a legitimate wait is microseconds
 
 // ---- the accumulators: in the ACCUMULATION registers a0 .. a159, behind the compiler's back.  A wave's ten 32 x 32 tiles
 // (tile t = ni * 2 + mi) live in a[16 t : 16 t + 15] for the whole kernel, and every access is inline assembly on literal
@@ -315,6 +315,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
     asm volatile("" : "+s"(zero_s));
     int ln = static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, static_cast<uint32_t>(zero_s))));
     int ext_iters = 0;
+    // FDNN_GEMM_DEBUG=4096 (tests): every third node tile pretends, in its first epilogue, that its wait for the siblings timed out
+    const bool sabotage = (p.debug & 4096) && ph == 1 && my_mt % 3 == 1;
     PPO_CLK(3 * (ph + 1));
     if (grp == cg) {
       // ============================================================== COMPUTE role
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
           const bool all_scaled = __builtin_amdgcn_readfirstlane(xf_s[4]) >= 4 * ph;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
-          if (all_scaled || ++ext_iters > kExtBound) break;
+          if (all_scaled || ++ext_iters > kExtBound || sabotage) break;
           xslot();
         }
       }
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
           const bool inv_ready = __builtin_amdgcn_readfirstlane(xf_s[3]) >= 3 * ph;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
-          if (all_scaled || ++ext_iters > kExtBound) break;
+          if (all_scaled || ++ext_iters > kExtBound || sabotage) break;
           if (inv_ready && !scaled) {
 #if !(FDNN_PPO_DEBUG & 32)
             // The outputs leave as WHOLE ROW SEGMENTS.  Straight from the accumulators' layout a store instruction is 32 frames

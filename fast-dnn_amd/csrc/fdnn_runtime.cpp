@@ -246,6 +246,8 @@ int make_ctx(fdnn_model *m, int n, fdnn_ctx **out, bool lean) {
     alloc(reinterpret_cast<void **>(&c->d_fuse_s), sizeof(float) * npt * mt);
     alloc(reinterpret_cast<void **>(&c->d_fuse_cnt), sizeof(uint32_t) * 8 * tiles);
     alloc(reinterpret_cast<void **>(&c->d_fuse_flag), sizeof(uint32_t) * tiles * mt);
+    c->fuse_cnt_bytes = sizeof(uint32_t) * 8 * tiles;
+    c->fuse_flag_bytes = sizeof(uint32_t) * tiles * mt;
     if (e == hipSuccess) e = hipMemset(c->d_fuse_cnt, 0, sizeof(uint32_t) * 8 * tiles);
     if (e == hipSuccess) e = hipMemset(c->d_fuse_flag, 0, sizeof(uint32_t) * tiles * mt);
   }
@@ -645,6 +647,12 @@ int run_output(fdnn_ctx *c, int first, int count, const int8_t *d_masks, float *
     g.frame_tile = fdnn::qppo_frame_tile();
     g.n_pad = round_up(count, g.frame_tile);
   }
+  if (fused && m->h_fuse_fault && __atomic_load_n(m->h_fuse_fault, __ATOMIC_RELAXED) != 0) {
+    // (fusing although a launch of this model gave up before -- FDNN_FUSE_NORM=1 / fdnn_debug_set_fuse(1): a workgroup that
+    // gave up may have left its exchange counters half counted; they are zeroed in stream order before every such launch)
+    HIP_TRY(hipMemsetAsync(c->d_fuse_cnt, 0, c->fuse_cnt_bytes, s));
+    HIP_TRY(hipMemsetAsync(c->d_fuse_flag, 0, c->fuse_flag_bytes, s));
+  }
   if (fused) {
     g.final = d_final ? d_final : d_out;
     g.fuse_s = c->d_fuse_s;
@@ -913,10 +921,21 @@ int calculate_on_one_device(fdnn_model *m, const float *x, int n, int dim, int b
   hipError_t e = ctx_enter(c, s);
   if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x, sizeof(float) * size_t(n) * dim, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
+    const bool fuse_fault_before = m->h_fuse_fault && __atomic_load_n(m->h_fuse_fault, __ATOMIC_RELAXED) != 0;
     rc = run_hidden(c, c->d_x, s, nullptr);
     if (!rc) rc = run_output(c, 0, n, nullptr, c->d_out, s, nullptr);
     if (!rc) rc = copy_out(out, c->d_out, sizeof(float) * size_t(n) * h.out_dim, s);
     if (rc) hipStreamSynchronize(s);
+    // copy_out has synchronised: did a fused soft-max workgroup of THIS pass sit out its bounded wait?  fdnn_gemm.hip's
+    // tiles finish such a frame tile after the fact, fdnn_ppo.hip's leave the half's rows unwritten (and say so through the
+    // same word): the output layer runs again -- unfused now, model_may_fuse has seen the word -- over the activations that
+    // are still in the context.  (Callers of the *_device entry points observe fdnn_model_fuse_giveups after their own
+    // synchronisation: INTEGRATION.md.)
+    if (!rc && m->h_fuse_fault && !fuse_fault_before && __atomic_load_n(m->h_fuse_fault, __ATOMIC_RELAXED) != 0) {
+      rc = run_output(c, 0, n, nullptr, c->d_out, s, nullptr);
+      if (!rc) rc = copy_out(out, c->d_out, sizeof(float) * size_t(n) * h.out_dim, s);
+      if (rc) hipStreamSynchronize(s);
+    }
     // copy_out has synchronised: did this pass's chained launch run into its wait bound?  Then what it computed on may not have
     // been written -- run the pass again, layer by layer (run_hidden sees the flag, re-zeroes the counters, stops chaining)
     if (!rc && c->h_chain_fault && __atomic_load_n(c->h_chain_fault, __ATOMIC_RELAXED) != 0 && !c->chain_broken) {

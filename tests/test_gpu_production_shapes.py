@@ -360,7 +360,10 @@ def test_fused_softmax_equals_the_scale_pass_and_its_give_up_path(net_model_path
     """Large dense batches scale the soft-max inside the output kernel (fused: exp(z) stays in registers, the 256-node
     tiles of a frame tile exchange row sums through memory).  Same bits as the unfused kernel + normalize pass
     (FDNN_FUSE_NORM=0), and the same bits again when every third node tile pretends its wait timed out
-    (FDNN_GEMM_DEBUG=4096): those tiles store that part of exp(z) unscaled and their frame tile's last workgroup finishes them."""
+    (FDNN_GEMM_DEBUG=4096): the in-phase tiles (the masked call here) store that part of exp(z) unscaled and their frame tile's
+    last workgroup finishes them; the role-split dense kernel (fdnn_ppo.hip: the dense call here) leaves its half's rows
+    unwritten, raises the model's fault word, and fdnn_calculate runs the output layer again, unfused.  Whichever call comes
+    first in a process meets the give-up (after it the model does not fuse any more): both orders."""
     import subprocess, sys
 
     code = f"""
@@ -370,20 +373,34 @@ from fast_dnn_amd import api, formats as F
 x = F.synth_features(10000, 432, seed=41)
 masks = F.generate_masks_fast(10000, 8000, 0.40, 0.03, seed=3)
 dnn = api.QuantizedDnn.loadFromFile({net_model_path!r})
-p = dnn.calculate(x)
-ctx = dnn.getNewLazyContext(10000)
-ctx.calculateUntilOutput(x)
-q = ctx.calculateForOutputNodesBatch(masks)
-ctx.delete(); dnn.delete()
+def dense():
+    return dnn.calculate(x)
+def lazy():
+    ctx = dnn.getNewLazyContext(10000)
+    ctx.calculateUntilOutput(x)
+    q_ = ctx.calculateForOutputNodesBatch(masks)
+    ctx.delete()
+    return q_
+if sys.argv[2] == "dense-first":
+    p = dense(); q = lazy()
+else:
+    q = lazy(); p = dense()
+print("GIVEUPS", dnn.fuseGiveups())
+dnn.delete()
 np.save(sys.argv[1], np.concatenate([p[::7], q[::7]]))
 """
     outs = []
-    for tag, env in (("fused", {}), ("unfused", {"FDNN_FUSE_NORM": "0"}), ("giveup", {"FDNN_GEMM_DEBUG": "4096"})):
+    for tag, env, order in (("fused", {}, "dense-first"), ("unfused", {"FDNN_FUSE_NORM": "0"}, "dense-first"), ("giveup_dense", {"FDNN_GEMM_DEBUG": "4096"}, "dense-first"),
+                            ("giveup_lazy", {"FDNN_GEMM_DEBUG": "4096"}, "lazy-first")):
         f = str(tmp_path / f"{tag}.npy")
-        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        r = subprocess.run([sys.executable, "-c", code, f, order], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
+        gave_up = int(r.stdout.split("GIVEUPS")[1].split()[0])
+        assert (gave_up > 0) == tag.startswith("giveup"), (tag, gave_up)
+        if tag.startswith("giveup"):
+            assert r.stderr.count("sat out its bounded wait") == 1
         outs.append(np.load(f))
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]) and np.array_equal(outs[0], outs[3])
     assert np.abs(outs[0].sum(1, dtype=np.float64) - 1).max() < 1e-4
 
 
