@@ -818,7 +818,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void qgemm_kernel(QGemmParams p) {
         if (tid < MT && fl_s[tid] != 0u) {
           __hip_atomic_store(p.fuse_flag + static_cast<size_t>(nt) * MT + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (p.fuse_giveups) atomicAdd(p.fuse_giveups, 1ull);  // observable: fdnn_model_fuse_giveups
-          if (p.fuse_fault) __hip_atomic_store(p.fuse_fault, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // ... and acted upon: run_output
+          if (p.fuse_fault) __hip_atomic_fetch_or(p.fuse_fault, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // ... and acted upon: run_output (bit 0: a give-up that was finished after the fact)
         }
       }
       if (tid == 0) {  // the counters are ready for the next launch

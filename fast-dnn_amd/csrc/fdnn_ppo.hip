@@ -705,7 +705,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_num_vgpr(96))) void q
         }
         if (!scaled && wm == 0 && ln == 0) {  // the siblings never arrived: this half's rows are missing, and it says so
           if (p.fuse_giveups) atomicAdd(p.fuse_giveups, 1ull);
-          if (p.fuse_fault) __hip_atomic_store(p.fuse_fault, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (p.fuse_fault) __hip_atomic_fetch_add(p.fuse_fault, 1ull << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // (upper half: halves left UNWRITTEN -- fdnn_calculate compares it around its pass)
         }
       }
     }

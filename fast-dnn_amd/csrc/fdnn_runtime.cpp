@@ -921,7 +921,7 @@ int calculate_on_one_device(fdnn_model *m, const float *x, int n, int dim, int b
   hipError_t e = ctx_enter(c, s);
   if (e == hipSuccess) e = hipMemcpyAsync(c->d_x, x, sizeof(float) * size_t(n) * dim, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
-    const bool fuse_fault_before = m->h_fuse_fault && __atomic_load_n(m->h_fuse_fault, __ATOMIC_RELAXED) != 0;
+    const unsigned long long unwritten_before = m->h_fuse_fault ? __atomic_load_n(m->h_fuse_fault, __ATOMIC_RELAXED) >> 32 : 0ull;
     rc = run_hidden(c, c->d_x, s, nullptr);
     if (!rc) rc = run_output(c, 0, n, nullptr, c->d_out, s, nullptr);
     if (!rc) rc = copy_out(out, c->d_out, sizeof(float) * size_t(n) * h.out_dim, s);
@@ -929,10 +929,13 @@ int calculate_on_one_device(fdnn_model *m, const float *x, int n, int dim, int b
     // copy_out has synchronised: did a fused soft-max workgroup of THIS pass sit out its bounded wait?  fdnn_gemm.hip's
     // tiles finish such a frame tile after the fact, fdnn_ppo.hip's leave the half's rows unwritten (and say so through the
     // same word): the output layer runs again -- unfused now, model_may_fuse has seen the word -- over the activations that
-    // are still in the context.  (Callers of the *_device entry points observe fdnn_model_fuse_giveups after their own
-    // synchronisation: INTEGRATION.md.)
-    if (!rc && m->h_fuse_fault && !fuse_fault_before && __atomic_load_n(m->h_fuse_fault, __ATOMIC_RELAXED) != 0) {
+    // are still in the context.  (The word's upper half counts such halves.  Callers of the *_device entry points observe
+    // fdnn_model_fuse_giveups after their own synchronisation: INTEGRATION.md.)
+    if (!rc && m->h_fuse_fault && (__atomic_load_n(m->h_fuse_fault, __ATOMIC_RELAXED) >> 32) != unwritten_before) {
+      const bool saved = c->no_fuse;
+      c->no_fuse = true;  // (whatever FDNN_FUSE_NORM says)
       rc = run_output(c, 0, n, nullptr, c->d_out, s, nullptr);
+      c->no_fuse = saved;
       if (!rc) rc = copy_out(out, c->d_out, sizeof(float) * size_t(n) * h.out_dim, s);
       if (rc) hipStreamSynchronize(s);
     }

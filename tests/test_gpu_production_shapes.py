@@ -390,8 +390,11 @@ dnn.delete()
 np.save(sys.argv[1], np.concatenate([p[::7], q[::7]]))
 """
     outs = []
-    for tag, env, order in (("fused", {}, "dense-first"), ("unfused", {"FDNN_FUSE_NORM": "0"}, "dense-first"), ("giveup_dense", {"FDNN_GEMM_DEBUG": "4096"}, "dense-first"),
-                            ("giveup_lazy", {"FDNN_GEMM_DEBUG": "4096"}, "lazy-first")):
+    # (FDNN_FUSE_NORM=1: this pytest process may hold the device's advisory marker -- it loaded models in earlier tests --, and
+    # a child that finds it taken would run unfused by itself: the fused variants must really fuse)
+    for tag, env, order in (("fused", {"FDNN_FUSE_NORM": "1"}, "dense-first"), ("unfused", {"FDNN_FUSE_NORM": "0"}, "dense-first"),
+                            ("giveup_dense", {"FDNN_FUSE_NORM": "1", "FDNN_GEMM_DEBUG": "4096"}, "dense-first"),
+                            ("giveup_lazy", {"FDNN_FUSE_NORM": "1", "FDNN_GEMM_DEBUG": "4096"}, "lazy-first")):
         f = str(tmp_path / f"{tag}.npy")
         r = subprocess.run([sys.executable, "-c", code, f, order], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
