@@ -743,12 +743,16 @@ bool qppo_ok(int rows, int rows_pad, int K, int n, bool fastdiv, bool has_fix) {
   const int mode = forced >= 0 ? forced : env_mode;
   if (mode == 0 || !fastdiv || K != kKT * kBK || rows_pad != kMT * kBM || (rows & 3) != 0) return false;
   if (mode == 1) return true;
-  // By default where it was measured ahead of the in-phase fused tiles (tools/ppo_time.py, several boxes; LABBOOK round 6):
-  // a layer without saturating pairs (trained nets) from 5 120 frames = two frame pairs per workgroup (10 000 frames: 191 ..
-  // 212 us against 218 .. 226, 20 480: 391 against 444, 5 120: 105 against 113); a layer with pairs -- the walk runs in a
-  // lone compute wave -- from 29 frame pairs (9 000 frames: 223 against 229, 10 000: 223 against 232, 12 000: 272 against
-  // 298, 16 000: 382 against 407; at 8 000 frames = 25 pairs on 8 slots it loses, 216 against 200).
-  return has_fix ? n > 28 * kFT : n >= 2 * kFT * 8;
+  // By default where it was measured ahead of the in-phase fused tiles (tools/ppo_time.py, several boxes; LABBOOK round 6).
+  // A launch is ceil(pairs / 8) rounds of frame pairs (8 slots of 32 workgroups on 256 CUs); what matters is how full the
+  // last round is and that a workgroup has at least two pairs (a steady state):
+  //   a layer without saturating pairs (trained nets): from 14 pairs when the rounds are >= 3/4 full -- 4 480 frames 102 us
+  //   against 105, 5 120: 105 / 113, 10 000: 191 .. 212 / 218 .. 226, 20 480: 391 / 444; 3 840 (12 pairs): 100 / 95;
+  //   a layer with pairs (the walk runs in a lone compute wave): from 22 pairs when the rounds are >= 4/5 full -- 7 000 frames
+  //   170 / 173, 7 680: 171 / 178, 8 320 .. 8 960: 217 / 224 .. 226, 10 000: 223 / 232, 12 000: 272 / 298, 16 000: 382 / 407;
+  //   8 000 (25 pairs: four rounds, the last with one pair): 216 / 200; 5 120: 123 / 117.
+  const int pairs = (n + kFT - 1) / kFT, rounds = (pairs + 7) / 8;
+  return has_fix ? pairs >= 22 && 5 * pairs >= 4 * 8 * rounds : pairs >= 14 && 4 * pairs >= 3 * 8 * rounds;
 }
 
 int qppo_frame_tile() { return kFT; }

@@ -314,8 +314,9 @@ FDNN_API int fdnn_debug_set_pp(int mode, int min_frames);
 /* How the OUTPUT layer of a large dense batch runs when its soft-max is fused: 1 = the role-split kernel (fdnn_ppo.hip: the
  * exchange of the 256-node row sums and the scale run beside the next half's k-loop) whenever the shape allows (8 000-node
  * class layer: 32 node tiles, 2 048 inputs, dense, validated division), 0 = fdnn_gemm.hip's in-phase fused tiles, -1 = the
- * default (FDNN_PPO in the environment, else: a layer without saturating weight pairs from 5 120 frames, one with pairs from
- * 8 961).  Process-wide; identical bits either way.
+ * default (FDNN_PPO in the environment, else by batch size: a layer without saturating weight pairs from 14 pairs of 160-frame
+ * halves = 4 161 frames, one with pairs from 22 = 6 721, in either case only where the launch's last round of frame pairs is
+ * at least 3/4 resp. 4/5 full -- fdnn_ppo.hip: qppo_ok).  Process-wide; identical bits either way.
  * CalculateOutput + SoftMax::apply, src/cpp/dnn.cc:428-454, :534-544, is what is being computed. */
 FDNN_API int fdnn_debug_set_ppo(int mode);
 

@@ -120,11 +120,11 @@ def test_role_split_output_with_corrections_firing_in_every_k_step(tmp_models, m
 
 def test_the_switch_and_the_default(net_model_path, modes):
     """fdnn_debug_set_ppo rejects values outside {-1, 0, 1}.  The default (-1) takes the role-split kernel for a layer with
-    saturating pairs from 8 961 frames (pair-free layers: from 5 120) -- whichever it takes, the bits are the same."""
+    saturating pairs from 22 frame pairs whose last round is 4/5 full (pair-free layers: 14 pairs, 3/4) -- whichever it takes, the bits are the same."""
     with pytest.raises(Exception):
         api.set_ppo(2)
     dnn = api.QuantizedDnn.loadFromFile(net_model_path)
-    for n in (6000, 8961, 12345):
+    for n in (6000, 7040, 8000, 12345):
         x = F.synth_features(n, 432, seed=900 + n % 7)
         d, gd = device_pass(dnn, x, -1)
         a, ga = device_pass(dnn, x, 0)
